@@ -1,0 +1,78 @@
+"""The CPU restatement (oracle/) against the reference's own outputs (tests/golden/, made by
+tools/make_golden.py from the compiled reference).  CPU only; pins the oracle."""
+import os
+
+import pytest
+
+import helpers
+import synth
+
+
+def _write(tmp_path, name, data):
+    p = tmp_path / name
+    p.write_bytes(data)
+    return str(p)
+
+
+def test_demo_scan_identical(oracle_build, golden_dir):
+    out = helpers.oracle_cli(oracle_build, "scan", os.path.join(golden_dir, "H19.fa"), os.path.join(golden_dir, "testDNA.fa"))
+    assert out == helpers.gunzip(os.path.join(golden_dir, "demo.scan.gz"))
+
+
+@pytest.mark.parametrize("name,opts", [
+    ("demo_lg40.TFOsorted", ["-lg", "40"]),
+    ("demo_default.TFOsorted", []),
+    ("demo_t1_r3.TFOsorted", ["-lg", "30", "-t", "1", "-r", "3"]),
+])
+def test_demo_tfosorted_identical(oracle_build, golden_dir, name, opts):
+    out = helpers.oracle_cli(oracle_build, "tfosorted", os.path.join(golden_dir, "H19.fa"),
+                             os.path.join(golden_dir, "testDNA.fa"), *opts)
+    assert out == open(os.path.join(golden_dir, name), "rb").read()
+
+
+def test_planted40k_scan_and_tfosorted(oracle_build, golden_dir):
+    rna, dna = os.path.join(golden_dir, "H19.fa"), os.path.join(golden_dir, "planted40k.fa")
+    out = helpers.oracle_cli(oracle_build, "scan", rna, dna, "-threads", "8")
+    gold = helpers.gunzip(os.path.join(golden_dir, "planted40k.scan.gz"))
+    assert out == gold
+    _, units = helpers.parse_scan(gold)
+    assert sum(u["stage1"] >= 251 for u in units) >= 20, "fixture must exercise the byte-overflow (Q1) path"
+    out = helpers.oracle_cli(oracle_build, "tfosorted", rna, dna, "-lg", "40", "-threads", "8")
+    assert out == open(os.path.join(golden_dir, "planted40k.TFOsorted"), "rb").read()
+
+
+def test_rnd30k(oracle_build, golden_dir, tmp_path):
+    dna = _write(tmp_path, "rnd30k.fa", b">syn|chrS|1-30000\n" + synth.random_dna(30000, 12345) + b"\n")
+    rna = os.path.join(golden_dir, "H19.fa")
+    out = helpers.oracle_cli(oracle_build, "scan", rna, dna, "-detail", "0", "-threads", "8")
+    assert out == helpers.gunzip(os.path.join(golden_dir, "rnd30k.scan.gz"))
+    out = helpers.oracle_cli(oracle_build, "tfosorted", rna, dna, "-lg", "40", "-threads", "8")
+    assert out == open(os.path.join(golden_dir, "rnd30k.TFOsorted"), "rb").read()
+
+
+def test_batch_vectors(oracle_build, golden_dir):
+    o = helpers.Oracle(oracle_build)
+    reqs = open(os.path.join(golden_dir, "batch.req")).read().splitlines()
+    rsps = open(os.path.join(golden_dir, "batch.rsp")).read().splitlines()
+    assert len(reqs) == len(rsps)
+    kinds = set()
+    for rq, rs in zip(reqs, rsps):
+        f, g = rq.split(" "), rs.split(" ")
+        q, t = f[1].encode(), f[2].encode()
+        kinds.add(f[0])
+        if f[0] == "S":
+            assert o.stage1_max(q, t) == int(g[1]), rq[:80]
+        elif f[0] == "P":
+            assert o.pre_align(q, t) == [int(x) for x in g[2:]], rq[:80]
+        elif f[0] == "K":
+            cands = o.candidates(o.pre_align(q, t), int(f[3]))
+            flat = [int(x) for x in g[2:]]
+            assert cands == list(zip(flat[0::2], flat[1::2])), rq[:80]
+        elif f[0] == "A":
+            five, cig = o.align(q, t)
+            exp = tuple(int(x) for x in g[1:6])
+            if exp[0] == 0:
+                assert five[0] == 0
+            else:
+                assert five == exp and (cig or "*") == g[6], rq[:80]
+    assert kinds == {"S", "P", "K", "A"}
