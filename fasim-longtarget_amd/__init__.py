@@ -1,0 +1,335 @@
+"""fasim-longtarget_amd: ctypes binding of libfasim_hip.so (include/fasim_hip.h).
+
+The package directory name contains a hyphen (it is fixed by the project layout), so import it with
+
+    import importlib.util, sys
+    spec = importlib.util.spec_from_file_location("fasim_longtarget_amd", ".../fasim-longtarget_amd/__init__.py")
+    mod = importlib.util.module_from_spec(spec); sys.modules[spec.name] = mod; spec.loader.exec_module(mod)
+
+or use the `load()` helper in `__graft_entry__.py`.
+
+Names mirror the reference's interface for this path: `calc_score_once` (stats.h:879), `ssw_pre_align`
+(ssw.h:128), `ssw_align` (ssw.h:118), `pick_candidates` (Aligner::preAlign, ssw_cpp.cpp:427-572), `scan`
+(= the body of LongTarget(), Fasim-LongTarget.cpp:379-598) and `tfosorted` (printResult(), :797-829).
+
+There is no CPU fallback: if the shared library is missing or no HIP device is usable, construction of
+`Engine` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfasim_hip.so")
+
+
+class FasimError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    """struct fasim_params -- defaults of initEnv() (Fasim-LongTarget.cpp:284-303)."""
+    _fields_ = [("rule", C.c_int32), ("cutLength", C.c_int32), ("strand", C.c_int32), ("overlapLength", C.c_int32),
+                ("ntMin", C.c_int32), ("ntMax", C.c_int32), ("scoreMin", C.c_float), ("minIdentity", C.c_float),
+                ("minStability", C.c_float), ("penaltyT", C.c_int32), ("penaltyC", C.c_int32), ("cDistance", C.c_int32),
+                ("cLength", C.c_int32)]
+
+
+class Alignment(C.Structure):
+    _fields_ = [("sw_score", C.c_int32), ("ref_begin", C.c_int32), ("ref_end", C.c_int32), ("query_begin", C.c_int32),
+                ("query_end", C.c_int32), ("cigar_len", C.c_int32), ("cigar", C.c_uint32 * 256)]
+
+    def cigar_string(self) -> str:
+        ops = "MIDNSHP=X"
+        return "".join(f"{c >> 4}{'M' if (c & 15) > 8 else ops[c & 15]}" for c in self.cigar[: self.cigar_len])
+
+
+class Triplex(C.Structure):
+    _fields_ = [("stari", C.c_int32), ("endi", C.c_int32), ("starj", C.c_int32), ("endj", C.c_int32), ("strand", C.c_int32),
+                ("reverse", C.c_int32), ("rule", C.c_int32), ("nt", C.c_int32), ("score", C.c_float), ("identity", C.c_float),
+                ("tri_score", C.c_float), ("seg", C.c_int32), ("enc", C.c_int32), ("reserved", C.c_int32),
+                ("tfo_off", C.c_int64), ("tts_off", C.c_int64)]
+
+
+class ScanStats(C.Structure):
+    _fields_ = [("segments", C.c_int64), ("segments_skipped", C.c_int64), ("units", C.c_int64), ("candidates", C.c_int64),
+                ("align_calls", C.c_int64), ("align_word_reruns", C.c_int64), ("stage2_overflow_units", C.c_int64),
+                ("stage1_word_reruns", C.c_int64), ("logical_cells", C.c_int64), ("t_total_s", C.c_double),
+                ("t_stage1_s", C.c_double), ("t_stage2_s", C.c_double), ("t_stage3_s", C.c_double), ("t_host_s", C.c_double)]
+
+
+class _Result(C.Structure):
+    _fields_ = [("recs", C.POINTER(Triplex)), ("count", C.c_int64), ("pool", C.POINTER(C.c_char)), ("pool_len", C.c_int64),
+                ("stats", ScanStats)]
+
+
+EXPORTS = ["fasim_params_default", "fasim_engine_create", "fasim_engine_destroy", "fasim_last_error", "fasim_set_query",
+           "fasim_calc_score_once", "fasim_ssw_pre_align", "fasim_pick_candidates", "fasim_ssw_align", "fasim_pre_align_batch",
+           "fasim_align_batch", "fasim_encode_unit", "fasim_scan", "fasim_result_free", "fasim_segment_count",
+           "fasim_tfosorted", "fasim_free", "fasim_synth_dna"]
+
+_lib = None
+
+
+def lib():
+    """Load libfasim_hip.so (fails loudly when it has not been built: run __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FasimError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = C.CDLL(LIB_PATH)
+    L.fasim_last_error.restype = C.c_char_p
+    L.fasim_last_error.argtypes = [C.c_void_p]
+    L.fasim_engine_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.fasim_engine_destroy.argtypes = [C.c_void_p]
+    L.fasim_engine_destroy.restype = None
+    L.fasim_params_default.argtypes = [C.POINTER(Params)]
+    L.fasim_params_default.restype = None
+    L.fasim_set_query.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
+    L.fasim_calc_score_once.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(C.c_int32)]
+    L.fasim_ssw_pre_align.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(C.c_int32)]
+    L.fasim_pick_candidates.argtypes = [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                        C.c_int32, C.POINTER(C.c_int32)]
+    L.fasim_ssw_align.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(Alignment)]
+    L.fasim_pre_align_batch.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int32,
+                                        C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.fasim_align_batch.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int32,
+                                    C.POINTER(Alignment)]
+    L.fasim_encode_unit.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_char_p, C.c_char_p]
+    L.fasim_scan.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(Params),
+                             C.POINTER(C.POINTER(_Result))]
+    L.fasim_result_free.argtypes = [C.POINTER(_Result)]
+    L.fasim_result_free.restype = None
+    L.fasim_segment_count.argtypes = [C.c_int64, C.POINTER(Params)]
+    L.fasim_segment_count.restype = C.c_int64
+    L.fasim_tfosorted.argtypes = [C.c_void_p, C.c_int64, C.c_char_p, C.c_int64, C.c_char_p, C.c_int64, C.POINTER(Params),
+                                  C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    L.fasim_free.argtypes = [C.c_void_p]
+    L.fasim_free.restype = None
+    L.fasim_synth_dna.argtypes = [C.c_char_p, C.c_int64, C.c_uint64]
+    L.fasim_synth_dna.restype = None
+    _lib = L
+    return L
+
+
+def default_params(**kw) -> Params:
+    p = Params()
+    lib().fasim_params_default(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+@dataclass
+class ScanResult:
+    """Records of one scan (or of one shard): raw bytes, ready to be gathered across ranks."""
+    recs: bytes          # count * sizeof(Triplex)
+    pool: bytes
+    stats: dict
+
+    @property
+    def count(self) -> int:
+        return len(self.recs) // C.sizeof(Triplex)
+
+    def triplexes(self):
+        arr = (Triplex * self.count).from_buffer_copy(self.recs)
+        out = []
+        for t in arr:
+            tfo = self.pool[t.tfo_off:self.pool.index(b"\0", t.tfo_off)]
+            tts = self.pool[t.tts_off:self.pool.index(b"\0", t.tts_off)]
+            out.append((t.stari, t.endi, t.starj, t.endj, t.strand, t.reverse, t.rule, t.nt, int(t.score),
+                        C.c_uint32.from_buffer_copy(C.c_float(t.identity)).value,
+                        C.c_uint32.from_buffer_copy(C.c_float(t.tri_score)).value, tfo, tts, t.seg, t.enc))
+        return out
+
+
+def merge_results(parts):
+    """Concatenate shard results in rank order (shards are contiguous segment ranges, so this IS the
+    canonical (segment, encoding, rank) order); pool offsets are rebased."""
+    recs, pool, base = [], [], 0
+    for r in parts:
+        arr = (Triplex * r.count).from_buffer_copy(r.recs) if r.count else []
+        for t in arr:
+            t.tfo_off += base
+            t.tts_off += base
+        recs.append(bytes(arr) if r.count else b"")
+        pool.append(r.pool)
+        base += len(r.pool)
+    return ScanResult(b"".join(recs), b"".join(pool), {})
+
+
+class Engine:
+    """One engine per GPU (one process per GPU in multi-GPU runs)."""
+
+    def __init__(self, device: int = 0):
+        self._L = lib()
+        h = C.c_void_p()
+        rc = self._L.fasim_engine_create(device, C.byref(h))
+        if rc != 0:
+            raise FasimError(f"fasim_engine_create({device}) failed ({rc}): {self._L.fasim_last_error(None).decode()}")
+        self._h = h
+        self.m = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.fasim_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise FasimError(f"libfasim_hip error {rc}: {self._L.fasim_last_error(self._h).decode()}")
+
+    def set_query(self, rna: bytes):
+        self._check(self._L.fasim_set_query(self._h, rna, len(rna)))
+        self.m = len(rna)
+
+    # --- single-problem drop-ins ------------------------------------------------------------------
+    def calc_score_once(self, target: bytes) -> int:
+        s = C.c_int32()
+        self._check(self._L.fasim_calc_score_once(self._h, target, len(target), C.byref(s)))
+        return s.value
+
+    def ssw_pre_align(self, target: bytes):
+        out = (C.c_int32 * len(target))()
+        self._check(self._L.fasim_ssw_pre_align(self._h, target, len(target), out))
+        return list(out)
+
+    def ssw_align(self, window: bytes) -> Alignment:
+        a = Alignment()
+        self._check(self._L.fasim_ssw_align(self._h, window, len(window), C.byref(a)))
+        return a
+
+    # --- batched ----------------------------------------------------------------------------------
+    @staticmethod
+    def _pack(seqs):
+        blob = b"".join(seqs)
+        n = len(seqs)
+        offs = (C.c_int64 * n)()
+        lens = (C.c_int32 * n)()
+        o = 0
+        for i, s in enumerate(seqs):
+            offs[i] = o
+            lens[i] = len(s)
+            o += len(s)
+        return blob, offs, lens
+
+    def pre_align_batch(self, targets, want_cols=True, want_stage1=True):
+        blob, offs, lens = self._pack(targets)
+        cols = (C.c_int32 * len(blob))() if want_cols else None
+        s1 = (C.c_int32 * len(targets))() if want_stage1 else None
+        self._check(self._L.fasim_pre_align_batch(self._h, blob, offs, lens, len(targets), cols, s1))
+        out_cols = None
+        if want_cols:
+            out_cols, o = [], 0
+            for t in targets:
+                out_cols.append(list(cols[o:o + len(t)]))
+                o += len(t)
+        return out_cols, (list(s1) if want_stage1 else None)
+
+    def align_batch(self, windows):
+        blob, offs, lens = self._pack(windows)
+        out = (Alignment * len(windows))()
+        self._check(self._L.fasim_align_batch(self._h, blob, offs, lens, len(windows), out))
+        return list(out)
+
+    # --- the LongTarget() body ----------------------------------------------------------------------
+    def scan(self, dna: bytes, params: Params | None = None, seg_first: int = 0, seg_count: int = -1) -> ScanResult:
+        p = params or default_params()
+        res = C.POINTER(_Result)()
+        self._check(self._L.fasim_scan(self._h, dna, len(dna), seg_first, seg_count, C.byref(p), C.byref(res)))
+        try:
+            r = res.contents
+            recs = C.string_at(r.recs, r.count * C.sizeof(Triplex)) if r.count else b""
+            pool = C.string_at(r.pool, r.pool_len) if r.pool_len else b""
+            stats = {k: getattr(r.stats, k) for k, _ in ScanStats._fields_}
+        finally:
+            self._L.fasim_result_free(res)
+        return ScanResult(recs, pool, stats)
+
+
+def pick_candidates(cols, threshold):
+    L = lib()
+    n = len(cols)
+    arr = (C.c_int32 * n)(*cols)
+    s = (C.c_int32 * (n + 1))()
+    p = (C.c_int32 * (n + 1))()
+    k = C.c_int32()
+    rc = L.fasim_pick_candidates(arr, n, threshold, s, p, n + 1, C.byref(k))
+    if rc != 0:
+        raise FasimError(L.fasim_last_error(None).decode())
+    return [(s[i], p[i]) for i in range(k.value)]
+
+
+def encode_unit(seg: bytes, enc: int):
+    L = lib()
+    t = C.create_string_buffer(len(seg) + 1)
+    s = C.create_string_buffer(len(seg) + 1)
+    rc = L.fasim_encode_unit(seg, len(seg), enc, t, s)
+    if rc != 0:
+        raise FasimError(L.fasim_last_error(None).decode())
+    return t.raw[:len(seg)], s.raw[:len(seg)].rstrip(b"\0")
+
+
+def segment_count(dna_len: int, params: Params | None = None) -> int:
+    p = params or default_params()
+    return lib().fasim_segment_count(dna_len, C.byref(p))
+
+
+def tfosorted(result: ScanResult, chr_name: str, start_genome: int, params: Params | None = None) -> bytes:
+    """-TFOsorted bytes for the (merged) records; host-side tail of the path."""
+    L = lib()
+    p = params or default_params()
+    text = C.c_void_p()
+    n = C.c_int64()
+    recs = C.create_string_buffer(result.recs, len(result.recs)) if result.recs else None
+    rc = L.fasim_tfosorted(C.cast(recs, C.c_void_p) if recs is not None else None, result.count, result.pool or b"\0",
+                           max(1, len(result.pool)), chr_name.encode(), start_genome, C.byref(p), C.byref(text), C.byref(n))
+    if rc != 0:
+        raise FasimError(f"fasim_tfosorted failed ({rc}): {L.fasim_last_error(None).decode()}")
+    try:
+        return C.string_at(text, n.value)
+    finally:
+        L.fasim_free(text)
+
+
+def synth_dna(n: int, seed: int) -> bytes:
+    buf = C.create_string_buffer(n)
+    lib().fasim_synth_dna(buf, n, seed)
+    return buf.raw[:n]
+
+
+def parse_dna_header(header: str):
+    """'>species|chr|start-end' -> (species, chr, start) like readDna() (Fasim-LongTarget.cpp:226-255)."""
+    species = chro = start = ""
+    tmp, j = "", 0
+    for c in header.lstrip(">"):
+        if c == "|" and j == 0:
+            species, tmp, j = tmp, "", 1
+        elif c == "|" and j == 1:
+            chro, tmp, j = tmp, "", 2
+        elif c == "-" and j == 2:
+            start, tmp = tmp, ""
+        else:
+            tmp += c
+    digits = ""
+    for c in start.strip():
+        if c.isdigit() or (c in "+-" and not digits):
+            digits += c
+        else:
+            break
+    try:
+        st = int(digits)
+    except ValueError:
+        st = 0
+    return species, chro, st

@@ -1,0 +1,56 @@
+// Descriptors shared by the host engine and the gfx950 kernels.
+#pragma once
+#include <stdint.h>
+
+namespace fasim {
+
+constexpr int GAP_OPEN = 16;   // cost of the first gap residue (ssw_cpp.cpp:244)
+constexpr int GAP_EXT = 4;     // each further residue (ssw_cpp.cpp:245)
+constexpr int BIAS = 4;        // |min(matrix)|, ssw_init (sswNew.cpp:1283-1286) / init_work (stats.h:404-419)
+
+// target / query letter codes on the device: A=0 C=1 G=2 T=3 other=4 ; 5 = pad row (score 0)
+constexpr int CODE_N = 4;
+constexpr int CODE_PAD = 5;
+
+// one striped Smith-Waterman problem = one 16-lane group
+struct StripedProb {
+	int64_t tbase;     // offset of the unit's first column in the target-code buffer
+	int32_t t0;        // first column of the window inside the unit
+	int32_t ref_len;   // number of columns
+	int32_t q_len;     // number of query rows (forward pass)
+	int32_t unit;      // output slot / provenance
+};
+
+// result of the forward+reverse passes of ssw_align (sswNew.cpp:1446-1525)
+struct AlignEnds {
+	int32_t score_fwd;   // 255 in byte mode = overflow -> must be re-run in word mode
+	int32_t ref_end;
+	int32_t read_end;
+	int32_t score_rev;
+	int32_t ref_begin;
+	int32_t read_begin;
+};
+
+// banded traceback problem (sswNew.cpp:1071-1259); one thread each
+struct BandProb {
+	int64_t tbase;       // target codes of the first column of the alignment rectangle
+	int32_t q_begin;     // first query row
+	int32_t ref_len, read_len;
+	int32_t score;
+	int64_t scratch_off; // byte offset of this problem's scratch region
+	int32_t scratch_cap; // bytes available
+	int32_t pad;
+};
+
+struct BandOut {
+	int32_t status;      // 0 ok, 1 = traceback error (reference returns NULL), 2 = scratch too small, 3 = undefined behaviour in the reference
+	int32_t cigar_len;
+	uint32_t cigar[62];
+};
+
+constexpr int MAX_CIGAR_DEV = 62;
+
+// packed 4-bit score table: entry q (0..5) of row t = score(t,q)+BIAS
+struct ScoreLut { uint32_t row[5]; };
+
+} // namespace fasim

@@ -1,0 +1,698 @@
+// fasim-longtarget_amd/csrc/engine.cpp -- host engine + C-ABI (include/fasim_hip.h) of libfasim_hip.so.
+//
+// Data layout in HBM (one engine = one GPU):
+//   dna        uint8[shard]                      the DNA shard, resident for the whole scan
+//   tcodes     uint8[nunit][tstride]             target codes of every (segment x encoding) unit of the batch
+//   colmax     uint8[nunit][tstride]             stage-2 column maxima (8-bit, as the reference's maxColumn)
+//   q1/q2      uint8[m]                          query codes under the stage-1 / stage-2 alphabets
+// Everything the kernels read is sized once per batch and reused; only small records cross PCIe.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/fasim_hip.h"
+#include "device_types.h"
+#include "host_post.h"
+#include "kernels.h"
+
+using namespace fasim;
+
+namespace {
+
+std::string g_last_error;
+
+struct DevBuf {
+	void* p = nullptr; size_t cap = 0;
+	hipError_t ensure(size_t bytes) {
+		if (bytes <= cap) return hipSuccess;
+		if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+		size_t want = bytes + bytes / 4 + 256;
+		hipError_t e = hipMalloc(&p, want);
+		if (e != hipSuccess) { p = nullptr; return e; }
+		cap = want;
+		return hipSuccess;
+	}
+	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+	template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+} // namespace
+
+struct fasim_engine {
+	int device = 0;
+	hipStream_t st = nullptr;
+	std::string err;
+	std::string rna;
+	int m = 0;
+	ScoreLut lut1, lut2;
+	DevBuf q1, q2, enc_lut, counter, dna, seg_start, seg_len, enc_ids, tcodes, colmax, probs, max_out, unit_len,
+		stage1, hits, hits_total, hit_off, hit_cnt, thr, ends, bprobs, bout, scratch;
+	int host_threads = 1;
+};
+
+namespace {
+
+int fail(fasim_engine* e, int code, const char* fmt, ...)
+{
+	char buf[1024];
+	va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+	g_last_error = buf;
+	if (e) e->err = buf;
+	return code;
+}
+
+#define HIPOK(call) do { hipError_t _e = (call); if (_e != hipSuccess) return fail(E, FASIM_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); } while (0)
+
+// stage-2/3 alphabet (ssw_cpp.cpp:13-26): A,a,U,u -> 0 ; C,c -> 1 ; G,g -> 2 ; T,t -> 3 ; else 4
+inline uint8_t code2(char c) { switch (c) { case 'A': case 'a': case 'U': case 'u': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; } }
+// stage-1 alphabet (stats.h:201-228, 306-334): U == T, everything outside ACGTU is N
+inline uint8_t code1(char c) { switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': case 'U': case 'u': return 3; default: return 4; } }
+
+ScoreLut make_lut(bool stage1)
+{
+	// row t, entry q (4 bits): score(t,q) + BIAS ; entry 5 = pad row = score 0
+	ScoreLut L;
+	for (int t = 0; t < 5; t++) {
+		uint32_t w = 0;
+		for (int q = 0; q < 5; q++) {
+			int s;
+			if (stage1) s = (t == 4 || q == 4) ? -1 : (t == q ? 5 : -4);      // npam: N row all -1 (stats.h:227-228)
+			else s = (t == q && t < 4) ? 5 : -4;                              // ssw_cpp.cpp:28-53
+			w |= (uint32_t)(s + BIAS) << (4 * q);
+		}
+		w |= (uint32_t)BIAS << 20;
+		L.row[t] = w;
+	}
+	return L;
+}
+
+// ---- a batch of units whose target codes are resident on the device ------------------------------
+struct UnitBatch {
+	int nunit = 0;
+	int tstride = 0;
+	std::vector<int> unit_len;      // columns per unit
+};
+
+int upload(fasim_engine* E, DevBuf& b, const void* src, size_t bytes)
+{
+	HIPOK(b.ensure(bytes ? bytes : 1));
+	// sources are short-lived pageable host vectors: make the copy complete before returning
+	if (bytes) { HIPOK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, E->st)); HIPOK(hipStreamSynchronize(E->st)); }
+	return FASIM_OK;
+}
+
+std::vector<StripedProb> whole_unit_probs(const UnitBatch& B, int m, const std::vector<int>* subset)
+{
+	std::vector<StripedProb> v;
+	const int n = subset ? (int)subset->size() : B.nunit;
+	v.reserve(n);
+	for (int k = 0; k < n; k++) {
+		const int u = subset ? (*subset)[k] : k;
+		StripedProb p; p.tbase = (int64_t)u * B.tstride; p.t0 = 0; p.ref_len = B.unit_len[u]; p.q_len = m; p.unit = u;
+		v.push_back(p);
+	}
+	return v;
+}
+
+int run_striped(fasim_engine* E, StripedMode mode, bool word, const std::vector<StripedProb>& probs, bool stage1,
+	const uint8_t* tcodes, int max_qlen)
+{
+	if (probs.empty()) return FASIM_OK;
+	int rc = upload(E, E->probs, probs.data(), probs.size() * sizeof(StripedProb));
+	if (rc) return rc;
+	StripedLaunch L;
+	L.tcodes = tcodes; L.qcodes = stage1 ? E->q1.as<uint8_t>() : E->q2.as<uint8_t>();
+	L.probs = E->probs.as<StripedProb>(); L.nprob = (int)probs.size(); L.counter = E->counter.as<uint32_t>();
+	L.lut = stage1 ? E->lut1 : E->lut2; L.max_qlen = max_qlen;
+	L.colmax = E->colmax.as<uint8_t>(); L.max_out = E->max_out.as<int32_t>(); L.ends = E->ends.as<AlignEnds>();
+	hipError_t he = launch_striped(mode, word, !stage1, L, E->st);
+	if (he == hipErrorInvalidValue) return fail(E, FASIM_E_UNSUPPORTED, "query of %d nt does not fit the LDS-resident striped kernel", max_qlen);
+	if (he != hipSuccess) return fail(E, FASIM_E_HIP, "striped kernel launch failed: %s", hipGetErrorString(he));
+	return FASIM_OK;
+}
+
+// stage 1 (a4): exact max per unit.  8-bit first, 16-bit re-run where the byte kernel overflowed.
+int run_stage1(fasim_engine* E, const UnitBatch& B, std::vector<int>& score, int64_t* word_reruns)
+{
+	score.assign(B.nunit, 0);
+	if (!B.nunit) return FASIM_OK;
+	HIPOK(E->max_out.ensure(sizeof(int32_t) * B.nunit));
+	int rc = run_striped(E, MODE_MAX1, false, whole_unit_probs(B, E->m, nullptr), true, E->tcodes.as<uint8_t>(), E->m);
+	if (rc) return rc;
+	HIPOK(hipMemcpyAsync(score.data(), E->max_out.p, sizeof(int32_t) * B.nunit, hipMemcpyDeviceToHost, E->st));
+	HIPOK(hipStreamSynchronize(E->st));
+	std::vector<int> redo;
+	for (int u = 0; u < B.nunit; u++) if (score[u] >= 255) redo.push_back(u);
+	if (!redo.empty()) {
+		rc = run_striped(E, MODE_MAX1, true, whole_unit_probs(B, E->m, &redo), true, E->tcodes.as<uint8_t>(), E->m);
+		if (rc) return rc;
+		std::vector<int> all(B.nunit);
+		HIPOK(hipMemcpyAsync(all.data(), E->max_out.p, sizeof(int32_t) * B.nunit, hipMemcpyDeviceToHost, E->st));
+		HIPOK(hipStreamSynchronize(E->st));
+		for (int u : redo) {
+			score[u] = all[u];
+			if (score[u] >= 32767) return fail(E, FASIM_E_OVERFLOW, "stage-1 score of unit %d left the 16-bit range", u);
+		}
+		if (word_reruns) *word_reruns += (int64_t)redo.size();
+	}
+	return FASIM_OK;
+}
+
+// stage 2 (a5/a6): column maxima into E->colmax
+int run_stage2(fasim_engine* E, const UnitBatch& B)
+{
+	if (!B.nunit) return FASIM_OK;
+	HIPOK(E->colmax.ensure((size_t)B.nunit * B.tstride));
+	HIPOK(E->max_out.ensure(sizeof(int32_t) * B.nunit));
+	return run_striped(E, MODE_PRE, false, whole_unit_probs(B, E->m, nullptr), false, E->tcodes.as<uint8_t>(), E->m);
+}
+
+struct WindowProb { int unit, t0, len; };
+
+// a9-a11: ssw_align for a list of windows (forward + reverse on the GPU, 16-bit re-runs, banded traceback)
+int run_align(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, std::vector<AlignResult>& out,
+	fasim_scan_stats* stats)
+{
+	const int n = (int)W.size();
+	out.assign(n, AlignResult());
+	if (!n) return FASIM_OK;
+	std::vector<StripedProb> probs(n);
+	for (int k = 0; k < n; k++) {
+		probs[k].tbase = (int64_t)W[k].unit * B.tstride; probs[k].t0 = W[k].t0; probs[k].ref_len = W[k].len;
+		probs[k].q_len = E->m; probs[k].unit = k;
+	}
+	HIPOK(E->ends.ensure(sizeof(AlignEnds) * n));
+	int rc = run_striped(E, MODE_ALIGN, false, probs, false, E->tcodes.as<uint8_t>(), E->m);
+	if (rc) return rc;
+	std::vector<AlignEnds> ends(n);
+	HIPOK(hipMemcpyAsync(ends.data(), E->ends.p, sizeof(AlignEnds) * n, hipMemcpyDeviceToHost, E->st));
+	HIPOK(hipStreamSynchronize(E->st));
+	std::vector<int> redo;
+	for (int k = 0; k < n; k++) if (ends[k].score_fwd == 255) redo.push_back(k);
+	if (!redo.empty()) {
+		// bests[0].score == 255 -> the whole alignment is redone with the 16-bit kernels (sswNew.cpp:1473-1477)
+		std::vector<StripedProb> wp(redo.size());
+		for (size_t r = 0; r < redo.size(); r++) { wp[r] = probs[redo[r]]; wp[r].unit = (int)r; }
+		rc = run_striped(E, MODE_ALIGN, true, wp, false, E->tcodes.as<uint8_t>(), E->m);
+		if (rc) return rc;
+		std::vector<AlignEnds> we(redo.size());
+		HIPOK(hipMemcpyAsync(we.data(), E->ends.p, sizeof(AlignEnds) * redo.size(), hipMemcpyDeviceToHost, E->st));
+		HIPOK(hipStreamSynchronize(E->st));
+		for (size_t r = 0; r < redo.size(); r++) ends[redo[r]] = we[r];
+		if (stats) stats->align_word_reruns += (int64_t)redo.size();
+	}
+	// banded traceback for every alignment with a positive score
+	std::vector<int> bidx;
+	std::vector<BandProb> bp;
+	for (int k = 0; k < n; k++) {
+		const AlignEnds& e = ends[k];
+		if (e.score_fwd <= 0 || e.ref_end < 0 || e.ref_begin < 0) continue;     // nothing aligned -> sw_score 0
+		const int rl = e.ref_end - e.ref_begin + 1, ql = e.read_end - e.read_begin + 1;
+		if (rl <= 0 || ql <= 0) continue;
+		BandProb b;
+		b.tbase = (int64_t)W[k].unit * B.tstride + W[k].t0 + e.ref_begin;
+		b.q_begin = e.read_begin; b.ref_len = rl; b.read_len = ql;
+		b.score = e.score_rev < e.score_fwd ? e.score_rev : e.score_fwd;          // sswNew.cpp:1518
+		b.scratch_off = 0; b.scratch_cap = 0; b.pad = 0;
+		bidx.push_back(k); bp.push_back(b);
+	}
+	std::vector<BandOut> bo(bp.size());
+	std::vector<int> todo(bp.size());
+	for (size_t i = 0; i < todo.size(); i++) todo[i] = (int)i;
+	size_t cap = 8192;
+	for (int attempt = 0; attempt < 4 && !todo.empty(); attempt++, cap *= 32) {
+		std::vector<BandProb> cur(todo.size());
+		// keep the scratch arena bounded: process in slices
+		const size_t max_arena = (size_t)6 << 30;
+		size_t per_slice = std::max<size_t>(1, max_arena / cap);
+		for (size_t s0 = 0; s0 < todo.size(); s0 += per_slice) {
+			const size_t cnt = std::min(per_slice, todo.size() - s0);
+			for (size_t i = 0; i < cnt; i++) { cur[i] = bp[todo[s0 + i]]; cur[i].scratch_off = (int64_t)(i * cap); cur[i].scratch_cap = (int)cap; }
+			HIPOK(E->scratch.ensure(cnt * cap));
+			HIPOK(E->bout.ensure(sizeof(BandOut) * cnt));
+			rc = upload(E, E->bprobs, cur.data(), sizeof(BandProb) * cnt);
+			if (rc) return rc;
+			hipError_t he = launch_banded(E->tcodes.as<uint8_t>(), E->q2.as<uint8_t>(), E->bprobs.as<BandProb>(), (int)cnt,
+				E->scratch.as<uint8_t>(), E->bout.as<BandOut>(), E->st);
+			if (he != hipSuccess) return fail(E, FASIM_E_HIP, "banded kernel launch failed: %s", hipGetErrorString(he));
+			std::vector<BandOut> tmp(cnt);
+			HIPOK(hipMemcpyAsync(tmp.data(), E->bout.p, sizeof(BandOut) * cnt, hipMemcpyDeviceToHost, E->st));
+			HIPOK(hipStreamSynchronize(E->st));
+			for (size_t i = 0; i < cnt; i++) bo[todo[s0 + i]] = tmp[i];
+		}
+		std::vector<int> next;
+		for (int i : todo) if (bo[i].status == 2) next.push_back(i);
+		todo.swap(next);
+	}
+	if (!todo.empty()) return fail(E, FASIM_E_UNSUPPORTED, "banded traceback of %zu alignments exceeds the scratch limit", todo.size());
+	for (size_t i = 0; i < bp.size(); i++) {
+		const int k = bidx[i];
+		const AlignEnds& e = ends[k];
+		AlignResult& r = out[k];
+		if (bo[i].status != 0) { r.sw_score = 0; continue; }    // NULL from ssw_align -> sw_score 0 (ssw_cpp.cpp:631-633)
+		r.sw_score = bp[i].score; r.ref_begin = e.ref_begin; r.ref_end = e.ref_end;
+		r.query_begin = e.read_begin; r.query_end = e.read_end;
+		r.cigar_len = bo[i].cigar_len;
+		memcpy(r.cigar, bo[i].cigar, sizeof(uint32_t) * bo[i].cigar_len);
+	}
+	return FASIM_OK;
+}
+
+// raw targets (letters) -> a UnitBatch whose codes use the given alphabet
+int load_raw_targets(fasim_engine* E, const char* targets, const int64_t* offsets, const int32_t* lens, int nprob,
+	bool stage1, UnitBatch& B)
+{
+	int maxlen = 1;
+	for (int i = 0; i < nprob; i++) { if (lens[i] <= 0) return fail(E, FASIM_E_ARG, "empty target %d", i); maxlen = std::max(maxlen, lens[i]); }
+	B.nunit = nprob; B.tstride = (maxlen + 15) & ~15; B.unit_len.assign(lens, lens + nprob);
+	std::vector<uint8_t> codes((size_t)nprob * B.tstride, CODE_N);
+	for (int i = 0; i < nprob; i++)
+		for (int c = 0; c < lens[i]; c++) codes[(size_t)i * B.tstride + c] = stage1 ? code1(targets[offsets[i] + c]) : code2(targets[offsets[i] + c]);
+	return upload(E, E->tcodes, codes.data(), codes.size());
+}
+
+int need_query(fasim_engine* E)
+{
+	if (!E) return fail(nullptr, FASIM_E_ARG, "null engine");
+	if (E->m <= 0) return fail(E, FASIM_E_ARG, "no query set: call fasim_set_query first");
+	return FASIM_OK;
+}
+
+} // namespace
+
+// =====================================================================================================
+// C-ABI
+// =====================================================================================================
+extern "C" {
+
+void fasim_params_default(fasim_params* p)
+{
+	p->rule = 0; p->cutLength = 5000; p->strand = 0; p->overlapLength = 100; p->ntMin = 20; p->ntMax = 100000;
+	p->scoreMin = 0.0f; p->minIdentity = 60.0f; p->minStability = 1.0f; p->penaltyT = -1000; p->penaltyC = 0;
+	p->cDistance = 15; p->cLength = 50;
+}
+
+const char* fasim_last_error(const fasim_engine* e) { return e ? e->err.c_str() : g_last_error.c_str(); }
+
+int fasim_engine_create(int device, fasim_engine** out)
+{
+	if (!out) return fail(nullptr, FASIM_E_ARG, "null out pointer");
+	*out = nullptr;
+	int count = 0;
+	hipError_t he = hipGetDeviceCount(&count);
+	if (he != hipSuccess || count <= 0) return fail(nullptr, FASIM_E_NODEVICE, "no HIP device available (%s); this library has no CPU fallback", hipGetErrorString(he));
+	if (device < 0 || device >= count) return fail(nullptr, FASIM_E_NODEVICE, "device %d out of range (%d devices)", device, count);
+	fasim_engine* E = new fasim_engine();
+	E->device = device;
+	he = hipSetDevice(device);
+	if (he == hipSuccess) he = hipStreamCreate(&E->st);
+	if (he != hipSuccess) { int rc = fail(nullptr, FASIM_E_NODEVICE, "cannot initialise device %d: %s", device, hipGetErrorString(he)); delete E; return rc; }
+	E->lut1 = make_lut(true); E->lut2 = make_lut(false);
+	std::vector<uint8_t> lut(48 * 256);
+	build_enc_lut(lut.data());
+	if (upload(E, E->enc_lut, lut.data(), lut.size()) || E->counter.ensure(64) != hipSuccess) { delete E; return FASIM_E_HIP; }
+	unsigned hc = std::thread::hardware_concurrency();
+	const char* env = getenv("FASIM_HOST_THREADS");
+	E->host_threads = env ? std::max(1, atoi(env)) : (int)std::min(32u, std::max(1u, hc));
+	*out = E;
+	return FASIM_OK;
+}
+
+void fasim_engine_destroy(fasim_engine* e)
+{
+	if (!e) return;
+	(void)hipSetDevice(e->device);
+	DevBuf* bufs[] = { &e->q1, &e->q2, &e->enc_lut, &e->counter, &e->dna, &e->seg_start, &e->seg_len, &e->enc_ids, &e->tcodes,
+		&e->colmax, &e->probs, &e->max_out, &e->unit_len, &e->stage1, &e->hits, &e->hits_total, &e->hit_off, &e->hit_cnt, &e->thr,
+		&e->ends, &e->bprobs, &e->bout, &e->scratch };
+	for (DevBuf* b : bufs) b->release();
+	if (e->st) (void)hipStreamDestroy(e->st);
+	delete e;
+}
+
+int fasim_set_query(fasim_engine* E, const char* rna, int32_t len)
+{
+	if (!E) return fail(nullptr, FASIM_E_ARG, "null engine");
+	if (!rna || len <= 0) return fail(E, FASIM_E_ARG, "empty query");
+	HIPOK(hipSetDevice(E->device));
+	E->rna.assign(rna, rna + len);
+	E->m = len;
+	std::vector<uint8_t> c1(len), c2(len);
+	for (int i = 0; i < len; i++) { c1[i] = code1(rna[i]); c2[i] = code2(rna[i]); }
+	int rc = upload(E, E->q1, c1.data(), len);
+	if (!rc) rc = upload(E, E->q2, c2.data(), len);
+	if (rc) return rc;
+	HIPOK(hipStreamSynchronize(E->st));
+	return FASIM_OK;
+}
+
+int fasim_pre_align_batch(fasim_engine* E, const char* targets, const int64_t* offsets, const int32_t* lens,
+	int32_t nprob, int32_t* out_cols, int32_t* out_stage1)
+{
+	int rc = need_query(E); if (rc) return rc;
+	if (!targets || !offsets || !lens || nprob <= 0) return fail(E, FASIM_E_ARG, "bad batch arguments");
+	HIPOK(hipSetDevice(E->device));
+	UnitBatch B;
+	if (out_stage1) {
+		rc = load_raw_targets(E, targets, offsets, lens, nprob, true, B); if (rc) return rc;
+		std::vector<int> sc;
+		rc = run_stage1(E, B, sc, nullptr); if (rc) return rc;
+		memcpy(out_stage1, sc.data(), sizeof(int32_t) * nprob);
+	}
+	if (out_cols) {
+		rc = load_raw_targets(E, targets, offsets, lens, nprob, false, B); if (rc) return rc;
+		rc = run_stage2(E, B); if (rc) return rc;
+		std::vector<uint8_t> cm((size_t)nprob * B.tstride);
+		HIPOK(hipMemcpyAsync(cm.data(), E->colmax.p, cm.size(), hipMemcpyDeviceToHost, E->st));
+		HIPOK(hipStreamSynchronize(E->st));
+		for (int i = 0; i < nprob; i++)
+			for (int c = 0; c < lens[i]; c++) out_cols[offsets[i] + c] = cm[(size_t)i * B.tstride + c];
+	}
+	return FASIM_OK;
+}
+
+int fasim_calc_score_once(fasim_engine* E, const char* target, int32_t n, int32_t* score)
+{
+	if (!target || !score) return fail(E, FASIM_E_ARG, "null argument");
+	const int64_t off = 0;
+	return fasim_pre_align_batch(E, target, &off, &n, 1, nullptr, score);
+}
+
+int fasim_ssw_pre_align(fasim_engine* E, const char* target, int32_t n, int32_t* out_cols)
+{
+	if (!target || !out_cols) return fail(E, FASIM_E_ARG, "null argument");
+	const int64_t off = 0;
+	return fasim_pre_align_batch(E, target, &off, &n, 1, out_cols, nullptr);
+}
+
+int fasim_pick_candidates(const int32_t* cols, int32_t n, int32_t threshold, int32_t* out_score, int32_t* out_pos,
+	int32_t cap, int32_t* count)
+{
+	if (!cols || !count || n < 0) return fail(nullptr, FASIM_E_ARG, "bad arguments");
+	std::vector<uint32_t> hits;
+	for (int c = 0; c < n; c++) if (cols[c] > threshold) hits.push_back(((uint32_t)c << 8) | (uint32_t)(cols[c] & 0xff));
+	std::vector<Cand> cands;
+	pick_candidates(hits.data(), (int)hits.size(), cands);
+	*count = (int)cands.size();
+	for (int i = 0; i < (int)cands.size() && i < cap; i++) { if (out_score) out_score[i] = cands[i].score; if (out_pos) out_pos[i] = cands[i].pos; }
+	return FASIM_OK;
+}
+
+int fasim_align_batch(fasim_engine* E, const char* windows, const int64_t* offsets, const int32_t* lens, int32_t nprob,
+	fasim_alignment* out)
+{
+	int rc = need_query(E); if (rc) return rc;
+	if (!windows || !offsets || !lens || !out || nprob <= 0) return fail(E, FASIM_E_ARG, "bad batch arguments");
+	HIPOK(hipSetDevice(E->device));
+	UnitBatch B;
+	rc = load_raw_targets(E, windows, offsets, lens, nprob, false, B); if (rc) return rc;
+	std::vector<WindowProb> W(nprob);
+	for (int i = 0; i < nprob; i++) { W[i].unit = i; W[i].t0 = 0; W[i].len = lens[i]; }
+	std::vector<AlignResult> res;
+	rc = run_align(E, B, W, res, nullptr); if (rc) return rc;
+	for (int i = 0; i < nprob; i++) {
+		out[i].sw_score = res[i].sw_score; out[i].ref_begin = res[i].ref_begin; out[i].ref_end = res[i].ref_end;
+		out[i].query_begin = res[i].query_begin; out[i].query_end = res[i].query_end; out[i].cigar_len = res[i].cigar_len;
+		memcpy(out[i].cigar, res[i].cigar, sizeof(uint32_t) * res[i].cigar_len);
+	}
+	return FASIM_OK;
+}
+
+int fasim_ssw_align(fasim_engine* E, const char* window, int32_t n, fasim_alignment* out)
+{
+	const int64_t off = 0;
+	return fasim_align_batch(E, window, &off, &n, 1, out);
+}
+
+int fasim_encode_unit(const char* seg, int32_t n, int32_t enc, char* target, char* src)
+{
+	if (!seg || n < 0 || enc < 0 || enc >= 48 || !target || !src) return fail(nullptr, FASIM_E_ARG, "bad arguments");
+	std::string t, s;
+	encode_unit_host(seg, n, enc, t, s);
+	memcpy(target, t.data(), n);
+	memset(src, 0, n);
+	memcpy(src, s.data(), s.size());
+	return FASIM_OK;
+}
+
+int64_t fasim_segment_count(int64_t dna_len, const fasim_params* p)
+{
+	// cutSequence (fastsim.h:71-90): pos += cut - overlap while pos < size
+	if (dna_len <= 0 || !p || p->cutLength - p->overlapLength <= 0) return 0;
+	const int64_t step = p->cutLength - p->overlapLength;
+	return (dna_len + step - 1) / step;
+}
+
+void fasim_result_free(fasim_result* r)
+{
+	if (!r) return;
+	free(r->recs); free(r->pool); free(r);
+}
+
+void fasim_free(void* p) { free(p); }
+
+void fasim_synth_dna(char* out, int64_t n, uint64_t seed)
+{
+	// splitmix64, 2 bits per base, 32 bases per word (tools/synth.py random_dna)
+	uint64_t s = seed;
+	for (int64_t i = 0; i < n; i += 32) {
+		s += 0x9E3779B97F4A7C15ull;
+		uint64_t z = s;
+		z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+		z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+		z ^= z >> 31;
+		for (int k = 0; k < 32 && i + k < n; k++) out[i + k] = "ACGT"[(z >> (2 * k)) & 3];
+	}
+}
+
+// ---- the batched body of LongTarget() ---------------------------------------------------------------
+int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_first, int64_t seg_count,
+	const fasim_params* pp, fasim_result** out)
+{
+	int rc = need_query(E); if (rc) return rc;
+	if (!dna || dna_len <= 0 || !pp || !out) return fail(E, FASIM_E_ARG, "bad arguments");
+	const fasim_params p = *pp;
+	if (p.cutLength <= 0 || p.cutLength - p.overlapLength <= 0) return fail(E, FASIM_E_ARG, "cutLength/overlapLength invalid");
+	if (dna_len > 0x7fffffffll) return fail(E, FASIM_E_ARG, "one record is limited to 2^31-1 nt (the reference's int positions)");
+	HIPOK(hipSetDevice(E->device));
+	const double t_begin = now_s();
+	fasim_scan_stats st; memset(&st, 0, sizeof st);
+
+	const int64_t nseg_all = fasim_segment_count(dna_len, &p);
+	if (seg_first < 0) seg_first = 0;
+	if (seg_count < 0 || seg_first + seg_count > nseg_all) seg_count = std::max<int64_t>(0, nseg_all - seg_first);
+	const int64_t step = p.cutLength - p.overlapLength;
+	const std::vector<int> encs = enabled_encodings(p);
+	const int nenc = (int)encs.size();
+
+	std::vector<HostTriplex> all;
+	if (seg_count > 0 && nenc > 0) {
+		// the shard's DNA stays resident for the whole scan
+		const int64_t shard_lo = seg_first * step;
+		const int64_t shard_hi = std::min<int64_t>(dna_len, (seg_first + seg_count - 1) * step + p.cutLength);
+		rc = upload(E, E->dna, dna + shard_lo, (size_t)(shard_hi - shard_lo)); if (rc) return rc;
+		rc = upload(E, E->enc_ids, encs.data(), sizeof(int) * nenc); if (rc) return rc;
+
+		const int tstride = (p.cutLength + 15) & ~15;
+		// batch size: bounded by memory for tcodes+colmax and by the stage-3 record volume
+		int64_t seg_batch = std::max<int64_t>(1, std::min<int64_t>(512, ((int64_t)3 << 30) / ((int64_t)2 * nenc * tstride)));
+		const char* envb = getenv("FASIM_SEG_BATCH");
+		if (envb) seg_batch = std::max(1, atoi(envb));
+
+		for (int64_t b0 = seg_first; b0 < seg_first + seg_count; b0 += seg_batch) {
+			const int64_t b1 = std::min(seg_first + seg_count, b0 + seg_batch);
+			// segments of this batch that are not skipped by same_seq()
+			std::vector<int32_t> sstart, slen; std::vector<int64_t> sidx;
+			for (int64_t s = b0; s < b1; s++) {
+				const int64_t pos = s * step;
+				const int len = (int)std::min<int64_t>(p.cutLength, dna_len - pos);
+				st.segments++;
+				if (same_seq(dna + pos, len)) { st.segments_skipped++; continue; }
+				sstart.push_back((int32_t)(pos - shard_lo)); slen.push_back(len); sidx.push_back(s);
+				st.logical_cells += (int64_t)E->m * len * nenc;
+			}
+			const int nseg = (int)sidx.size();
+			if (!nseg) continue;
+			UnitBatch B; B.nunit = nseg * nenc; B.tstride = tstride; B.unit_len.resize(B.nunit);
+			for (int s = 0; s < nseg; s++) for (int k = 0; k < nenc; k++) B.unit_len[s * nenc + k] = slen[s];
+			st.units += B.nunit;
+			rc = upload(E, E->seg_start, sstart.data(), sizeof(int32_t) * nseg); if (rc) return rc;
+			rc = upload(E, E->seg_len, slen.data(), sizeof(int32_t) * nseg); if (rc) return rc;
+			rc = upload(E, E->unit_len, B.unit_len.data(), sizeof(int32_t) * B.nunit); if (rc) return rc;
+			HIPOK(E->tcodes.ensure((size_t)B.nunit * tstride));
+			hipError_t he = launch_encode(E->dna.as<uint8_t>(), E->seg_start.as<int32_t>(), E->seg_len.as<int32_t>(), nseg,
+				E->enc_ids.as<int32_t>(), nenc, E->enc_lut.as<uint8_t>(), E->tcodes.as<uint8_t>(), tstride, E->st);
+			if (he != hipSuccess) return fail(E, FASIM_E_HIP, "encode launch failed: %s", hipGetErrorString(he));
+
+			// ---- stage 1
+			double t0 = now_s();
+			std::vector<int> s1;
+			rc = run_stage1(E, B, s1, &st.stage1_word_reruns); if (rc) return rc;
+			st.t_stage1_s += now_s() - t0;
+
+			// ---- stage 2 + hits
+			t0 = now_s();
+			rc = run_stage2(E, B); if (rc) return rc;
+			rc = upload(E, E->stage1, s1.data(), sizeof(int32_t) * B.nunit); if (rc) return rc;
+			HIPOK(E->hit_off.ensure(sizeof(int32_t) * B.nunit)); HIPOK(E->hit_cnt.ensure(sizeof(int32_t) * B.nunit));
+			HIPOK(E->thr.ensure(sizeof(int32_t) * B.nunit)); HIPOK(E->hits_total.ensure(64));
+			std::vector<int32_t> hoff(B.nunit), hcnt(B.nunit), thr(B.nunit), pre_max(B.nunit);
+			std::vector<uint32_t> hits;
+			size_t hits_cap = std::max<size_t>(E->hits.cap / 4, (size_t)B.nunit * 128);
+			for (;;) {
+				HIPOK(E->hits.ensure(hits_cap * sizeof(uint32_t)));
+				he = launch_hits(E->colmax.as<uint8_t>(), E->unit_len.as<int32_t>(), E->stage1.as<int32_t>(), B.nunit, tstride,
+					E->hits.as<uint32_t>(), (uint32_t)hits_cap, E->hits_total.as<uint32_t>(), E->hit_off.as<int32_t>(),
+					E->hit_cnt.as<int32_t>(), E->thr.as<int32_t>(), E->st);
+				if (he != hipSuccess) return fail(E, FASIM_E_HIP, "hits launch failed: %s", hipGetErrorString(he));
+				uint32_t total = 0;
+				HIPOK(hipMemcpyAsync(&total, E->hits_total.p, sizeof total, hipMemcpyDeviceToHost, E->st));
+				HIPOK(hipStreamSynchronize(E->st));
+				if (total <= hits_cap) { hits.resize(total); break; }
+				hits_cap = (size_t)total + 1024;
+			}
+			HIPOK(hipMemcpyAsync(hoff.data(), E->hit_off.p, sizeof(int32_t) * B.nunit, hipMemcpyDeviceToHost, E->st));
+			HIPOK(hipMemcpyAsync(hcnt.data(), E->hit_cnt.p, sizeof(int32_t) * B.nunit, hipMemcpyDeviceToHost, E->st));
+			HIPOK(hipMemcpyAsync(thr.data(), E->thr.p, sizeof(int32_t) * B.nunit, hipMemcpyDeviceToHost, E->st));
+			HIPOK(hipMemcpyAsync(pre_max.data(), E->max_out.p, sizeof(int32_t) * B.nunit, hipMemcpyDeviceToHost, E->st));
+			if (!hits.empty()) HIPOK(hipMemcpyAsync(hits.data(), E->hits.p, sizeof(uint32_t) * hits.size(), hipMemcpyDeviceToHost, E->st));
+			HIPOK(hipStreamSynchronize(E->st));
+			for (int u = 0; u < B.nunit; u++) if (pre_max[u] == 255) st.stage2_overflow_units++;
+			st.t_stage2_s += now_s() - t0;
+
+			// ---- candidates (a7) and the window tries (a8) in up to 4 rounds
+			t0 = now_s();
+			struct CandState { int unit; Cand c; int done; AlignResult al; int cut; AlignResult best; int bestcut; int flag; };
+			std::vector<CandState> cs;
+			{
+				std::vector<Cand> tmp;
+				for (int u = 0; u < B.nunit; u++) {
+					pick_candidates(hits.data() + hoff[u], hcnt[u], tmp);
+					for (const Cand& c : tmp) { CandState x; x.unit = u; x.c = c; x.done = 0; x.cut = 0; x.bestcut = 0; x.flag = 0; cs.push_back(x); }
+				}
+			}
+			st.candidates += (int64_t)cs.size();
+			for (int it = 0; it < 4; it++) {
+				std::vector<WindowProb> W; std::vector<int> who;
+				for (size_t k = 0; k < cs.size(); k++) {
+					if (cs[k].done) continue;
+					int cut;
+					if (!window_for_try(it, cs[k].c.score, cs[k].c.pos, &cut)) { cs[k].done = 1; continue; }
+					cs[k].cut = cut;
+					W.push_back({ cs[k].unit, cs[k].c.pos - cut + 1, cut });
+					who.push_back((int)k);
+				}
+				if (W.empty()) break;
+				st.align_calls += (int64_t)W.size();
+				std::vector<AlignResult> res;
+				rc = run_align(E, B, W, res, &st); if (rc) return rc;
+				for (size_t i = 0; i < who.size(); i++) {
+					CandState& x = cs[who[i]];
+					x.al = res[i];
+					if (x.al.sw_score >= x.c.score) { x.flag = 1; x.done = 1; continue; }                    // fastsim.h:218-221
+					if (x.al.sw_score > x.best.sw_score && x.al.ref_end == x.cut - 1) { x.best = x.al; x.bestcut = x.cut; x.flag = 2; }   // :222-235
+				}
+			}
+			st.t_stage3_s += now_s() - t0;
+
+			// ---- host: triplex records per unit (a12-a14), then LongTarget()'s tail filter (a15)
+			t0 = now_s();
+			std::vector<std::vector<HostTriplex>> per_unit(B.nunit);
+			{
+				std::vector<size_t> first(B.nunit + 1, 0);
+				for (const CandState& x : cs) first[x.unit + 1]++;
+				for (int u = 0; u < B.nunit; u++) first[u + 1] += first[u];
+				std::atomic<int> next(0);
+				auto work = [&]() {
+					for (;;) {
+						const int u = next.fetch_add(1);
+						if (u >= B.nunit) break;
+						if (first[u] == first[u + 1]) continue;
+						const int s = u / nenc, enc = encs[u % nenc];
+						const char* seg = dna + sidx[s] * step;
+						const long dna_start = (long)(sidx[s] * step);
+						std::vector<HostTriplex> mine;
+						for (size_t k = first[u]; k < first[u + 1]; k++) {
+							CandState& x = cs[k];
+							AlignResult al = x.al; int cut = x.cut;
+							if (x.flag == 2) { al = x.best; cut = x.bestcut; }                                  // fastsim.h:238-250
+							if (al.sw_score == 0) continue;                                                    // :253
+							al.ref_begin += x.c.pos - cut + 1; al.ref_end += x.c.pos - cut + 1;                // :254-255
+							convert_triplex(al, E->rna, seg, slen[s], enc, dna_start, p, mine);
+						}
+						dedup_top(mine, p, per_unit[u]);
+						for (HostTriplex& t : per_unit[u]) { t.seg = (int)sidx[s]; t.enc = enc; }
+					}
+				};
+				const int nt = std::max(1, std::min(E->host_threads, B.nunit));
+				if (nt == 1) work();
+				else { std::vector<std::thread> th; for (int k = 0; k < nt; k++) th.emplace_back(work); for (auto& t : th) t.join(); }
+			}
+			for (int u = 0; u < B.nunit; u++)
+				for (HostTriplex& t : per_unit[u])
+					if (t.score >= p.scoreMin && t.identity >= p.minIdentity && t.tri_score >= p.minStability && t.nt >= p.cLength)   // Fasim-LongTarget.cpp:589-597
+						all.push_back(std::move(t));
+			st.t_host_s += now_s() - t0;
+		}
+	}
+
+	// pack the records
+	fasim_result* R = (fasim_result*)calloc(1, sizeof(fasim_result));
+	if (!R) return fail(E, FASIM_E_NOMEM, "out of memory");
+	size_t pool = 0;
+	for (const HostTriplex& t : all) pool += t.tfo.size() + t.tts.size() + 2;
+	R->count = (int64_t)all.size();
+	R->recs = (fasim_triplex*)calloc(std::max<size_t>(1, all.size()), sizeof(fasim_triplex));
+	R->pool = (char*)calloc(std::max<size_t>(1, pool), 1);
+	if (!R->recs || !R->pool) { fasim_result_free(R); return fail(E, FASIM_E_NOMEM, "out of memory"); }
+	R->pool_len = (int64_t)pool;
+	size_t off = 0;
+	for (size_t i = 0; i < all.size(); i++) {
+		const HostTriplex& t = all[i];
+		fasim_triplex& r = R->recs[i];
+		r.stari = t.stari; r.endi = t.endi; r.starj = t.starj; r.endj = t.endj; r.strand = t.strand; r.reverse = t.reverse;
+		r.rule = t.rule; r.nt = t.nt; r.score = t.score; r.identity = t.identity; r.tri_score = t.tri_score; r.seg = t.seg; r.enc = t.enc;
+		r.tfo_off = (int64_t)off; memcpy(R->pool + off, t.tfo.c_str(), t.tfo.size() + 1); off += t.tfo.size() + 1;
+		r.tts_off = (int64_t)off; memcpy(R->pool + off, t.tts.c_str(), t.tts.size() + 1); off += t.tts.size() + 1;
+	}
+	st.t_total_s = now_s() - t_begin;
+	R->stats = st;
+	*out = R;
+	return FASIM_OK;
+}
+
+int fasim_tfosorted(const fasim_triplex* recs, int64_t count, const char* pool, int64_t pool_len, const char* chr,
+	int64_t start_genome, const fasim_params* p, char** text, int64_t* text_len)
+{
+	if ((count > 0 && (!recs || !pool)) || !chr || !p || !text || !text_len || count < 0) return fail(nullptr, FASIM_E_ARG, "bad arguments");
+	std::vector<HostTriplex> list((size_t)count);
+	for (int64_t i = 0; i < count; i++) {
+		const fasim_triplex& r = recs[i];
+		if (r.tfo_off < 0 || r.tfo_off >= pool_len || r.tts_off < 0 || r.tts_off >= pool_len) return fail(nullptr, FASIM_E_ARG, "record %lld points outside the pool", (long long)i);
+		HostTriplex& t = list[(size_t)i];
+		t.stari = r.stari; t.endi = r.endi; t.starj = r.starj; t.endj = r.endj; t.strand = r.strand; t.reverse = r.reverse;
+		t.rule = r.rule; t.nt = r.nt; t.score = r.score; t.identity = r.identity; t.tri_score = r.tri_score; t.seg = r.seg; t.enc = r.enc;
+		t.tfo = pool + r.tfo_off; t.tts = pool + r.tts_off;
+		if (t.nt > p->cLength && (t.stari + t.endi) / 2 - p->cDistance < 0)
+			return fail(nullptr, FASIM_E_UNSUPPORTED, "a triplex mid-point lies within -ds of the query start: the reference's clustering does not terminate for this input");
+	}
+	std::string s = tfosorted_text(list, chr, (long)start_genome, *p);
+	char* buf = (char*)malloc(s.size() + 1);
+	if (!buf) return fail(nullptr, FASIM_E_NOMEM, "out of memory");
+	memcpy(buf, s.data(), s.size()); buf[s.size()] = 0;
+	*text = buf; *text_len = (int64_t)s.size();
+	return FASIM_OK;
+}
+
+} // extern "C"

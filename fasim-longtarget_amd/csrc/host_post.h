@@ -1,0 +1,51 @@
+// Host-side half of the path: peak picking, the window policy, triplex
+// construction, de-duplication, clustering and the -TFOsorted writer.  Integer/float order follows the
+// reference exactly (file:line cited at each function in host_post.cpp).
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/fasim_hip.h"
+
+namespace fasim {
+
+struct EncInfo { int strand, para, rule; bool reversed; };
+EncInfo enc_info(int enc);
+const char* rule_out(int enc);                       // outputs for DNA letters A,T,G,C
+void build_enc_lut(uint8_t* lut /*[48][256]*/);      // DNA byte -> target code (A0 C1 G2 T3 N4)
+std::vector<int> enabled_encodings(const fasim_params& p);
+void encode_unit_host(const char* seg, int n, int enc, std::string& target, std::string& src);
+bool same_seq(const char* seg, int n);
+
+struct Cand { int score, pos; };
+void pick_candidates(const uint32_t* hits, int nhits, std::vector<Cand>& out);   // hits = (pos<<8)|score, ascending pos
+
+struct AlignResult {
+	int sw_score = 0, ref_begin = 0, ref_end = 0, query_begin = 0, query_end = 0;
+	int cigar_len = 0;
+	uint32_t cigar[62];
+};
+
+// window length tried at iteration `it` (0..3) for a candidate (fastsim.h:204-211); returns false when the
+// loop `while (Iden <= 1)` has ended
+bool window_for_try(int it, int cand_score, int cand_pos, int* cutlength);
+
+struct HostTriplex {
+	int stari, endi, starj, endj, strand, reverse, rule, nt;
+	float score, identity, tri_score;
+	std::string tfo, tts;
+	int seg = 0, enc = 0;
+	int middle = 0, center = 0, motif = 0, neartriplex = 0;
+	long genomestart = 0, genomeend = 0;
+};
+
+// convertMyTriplex (fastsim.h:291-414): appends to `list` when nt >= ntMin
+void convert_triplex(const AlignResult& al, const std::string& rna, const char* seg, int n, int enc,
+	long dna_start, const fasim_params& p, std::vector<HostTriplex>& list);
+// tail of fastSIM (fastsim.h:273-288): sort/unique/sort/unique/sort, top 50, identity/stability/nt filter
+void dedup_top(std::vector<HostTriplex>& mine, const fasim_params& p, std::vector<HostTriplex>& out);
+
+void cluster_triplex(int dd, int length, std::vector<HostTriplex>& list);
+std::string tfosorted_text(std::vector<HostTriplex>& list, const std::string& chr, long start_genome, const fasim_params& p);
+
+} // namespace fasim

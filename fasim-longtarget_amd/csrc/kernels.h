@@ -1,0 +1,40 @@
+// Host-callable launchers of the gfx950 kernels (defined in kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "device_types.h"
+
+namespace fasim {
+
+enum StripedMode { MODE_PRE = 0, MODE_MAX1 = 1, MODE_ALIGN = 2 };
+
+struct StripedLaunch {
+	const uint8_t* tcodes;      // device: target codes
+	const uint8_t* qcodes;      // device: query codes (stage-1 or stage-2 coding), length q_total
+	const StripedProb* probs;   // device
+	int32_t nprob;
+	uint32_t* counter;          // device: work-queue head, zeroed by the launcher
+	ScoreLut lut;
+	int32_t max_qlen;           // largest q_len in the batch (sizes the LDS stripes)
+	uint8_t* colmax;            // MODE_PRE: u8 column maxima, same indexing as tcodes
+	int32_t* max_out;           // MODE_PRE / MODE_MAX1: per problem (slot = prob.unit) score, 255 = byte overflow
+	AlignEnds* ends;            // MODE_ALIGN: per problem (slot = index in probs)
+};
+
+// word == false: 8-bit semantics (16 stripes); word == true: 16-bit semantics (8 stripes)
+// quirk: reproduce the signed lazy-F exit test of the SSW byte kernels (sswNew.cpp:369,590)
+hipError_t launch_striped(StripedMode mode, bool word, bool quirk, const StripedLaunch& a, hipStream_t st);
+
+// target codes of every (segment, encoding) unit: tcodes[(seg*nenc + k)*tstride + c]
+hipError_t launch_encode(const uint8_t* dna_dev, const int32_t* seg_start, const int32_t* seg_len, int32_t nseg,
+	const int32_t* enc_ids, int32_t nenc, const uint8_t* enc_lut /*[48][256] -> code*/, uint8_t* tcodes,
+	int32_t tstride, hipStream_t st);
+
+// hits above threshold, ordered by column, per unit.  hits[] entries = (pos << 8) | score
+hipError_t launch_hits(const uint8_t* colmax, const int32_t* unit_len, const int32_t* stage1, int32_t nunit,
+	int32_t tstride, uint32_t* hits, uint32_t hits_cap, uint32_t* hits_total, int32_t* hit_off, int32_t* hit_cnt,
+	int32_t* thr_out, hipStream_t st);
+
+hipError_t launch_banded(const uint8_t* tcodes, const uint8_t* qcodes, const BandProb* probs, int32_t nprob,
+	uint8_t* scratch, BandOut* out, hipStream_t st);
+
+} // namespace fasim

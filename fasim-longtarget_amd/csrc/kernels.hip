@@ -1,0 +1,548 @@
+// fasim-longtarget_amd/csrc/kernels.hip -- gfx950 (MI355X) kernels of the triplex scan hot path.
+//
+//   k_encode    rule encodings (rules.h:94-318 transferString / reverseSeq) -> target codes per unit
+//   k_striped   stripe-faithful Smith-Waterman: one 16-lane DPP row per problem, 4 problems per wave64,
+//               problems pulled from a device work queue.  Three modes:
+//                 MODE_PRE    sw_sse2_byte_once (sswNew.cpp:255-464): column maxima incl. Q1 break, Q2, Q3
+//                 MODE_MAX1   calc_score_once (stats.h:879-956): exact max (8-bit, re-run in 16-bit on overflow)
+//                 MODE_ALIGN  forward + reverse pass of ssw_align (sswNew.cpp:1446-1525)
+//   k_hits      columns above the unit's threshold, ordered (first half of Aligner::preAlign, ssw_cpp.cpp:446-457)
+//   k_banded    banded_sw traceback (sswNew.cpp:1071-1259), one thread per alignment
+//
+// Integer DP: no MFMA.  H/E columns and the striped query live in LDS; stripe-to-stripe hand-over of the
+// diagonal H and of the lazy-F value uses 16-wide wave shuffles; target codes are read 16 columns at a
+// time (one coalesced byte per lane) and broadcast by shuffle.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include "kernels.h"
+
+namespace fasim {
+
+// ------------------------------------------------------------------------------------------------
+// k_encode
+// ------------------------------------------------------------------------------------------------
+__global__ void k_encode(const uint8_t* __restrict__ dna, const int32_t* __restrict__ seg_start,
+	const int32_t* __restrict__ seg_len, const int32_t* __restrict__ enc_ids, int32_t nenc,
+	const uint8_t* __restrict__ enc_lut, uint8_t* __restrict__ tcodes, int32_t tstride)
+{
+	const int unit = blockIdx.x;                 // seg * nenc + k
+	const int seg = unit / nenc, k = unit - seg * nenc;
+	const int enc = enc_ids[k];
+	const int n = seg_len[seg];
+	const int64_t s0 = seg_start[seg];
+	const bool rev = (enc & 1) != 0;             // odd encodings are the reversed ones (Fasim-LongTarget.cpp:428,520)
+	const uint8_t* lut = enc_lut + enc * 256;
+	for (int c = threadIdx.x; c < tstride; c += blockDim.x) {
+		const int src = rev ? (n - 1 - c) : c;
+		tcodes[(int64_t)unit * tstride + c] = c < n ? lut[dna[s0 + src]] : (uint8_t)CODE_N;
+	}
+}
+
+hipError_t launch_encode(const uint8_t* dna_dev, const int32_t* seg_start, const int32_t* seg_len, int32_t nseg,
+	const int32_t* enc_ids, int32_t nenc, const uint8_t* enc_lut, uint8_t* tcodes, int32_t tstride, hipStream_t st)
+{
+	if (nseg <= 0 || nenc <= 0) return hipSuccess;
+	hipLaunchKernelGGL(k_encode, dim3((unsigned)(nseg * nenc)), dim3(256), 0, st, dna_dev, seg_start, seg_len, enc_ids, nenc,
+		enc_lut, tcodes, tstride);
+	return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_striped
+// ------------------------------------------------------------------------------------------------
+struct StripedArgs {
+	const uint8_t* tcodes;
+	const uint8_t* qcodes;
+	const StripedProb* probs;
+	int32_t nprob;
+	uint32_t* counter;
+	ScoreLut lut;
+	int32_t s4;                 // bytes-of-rows stride of one stripe in LDS (multiple of 4, (s4/4) odd)
+	uint8_t* colmax;
+	int32_t* max_out;
+	AlignEnds* ends;
+};
+
+__device__ __forceinline__ int group_max16(int v)
+{
+	v = max(v, __shfl_xor(v, 8, 16));
+	v = max(v, __shfl_xor(v, 4, 16));
+	v = max(v, __shfl_xor(v, 2, 16));
+	v = max(v, __shfl_xor(v, 1, 16));
+	return v;
+}
+__device__ __forceinline__ int group_min16(int v)
+{
+	v = min(v, __shfl_xor(v, 8, 16));
+	v = min(v, __shfl_xor(v, 4, 16));
+	v = min(v, __shfl_xor(v, 2, 16));
+	v = min(v, __shfl_xor(v, 1, 16));
+	return v;
+}
+// true if any lane of this 16-lane group has c set
+__device__ __forceinline__ bool group_any16(bool c)
+{
+	const unsigned long long b = __ballot(c);
+	const int sh = (threadIdx.x & 63) & 48;
+	return ((b >> sh) & 0xffffull) != 0;
+}
+
+// One column of the 8-bit kernel for this lane's stripe.  Returns the lane's column maximum.
+// (main loop sswNew.cpp:332-357 / stats.h:673-689, lazy-F loop sswNew.cpp:360-371)
+template <bool QUIRK>
+__device__ __forceinline__ int column_byte(uint8_t* Hs, uint8_t* Es, const uint8_t* Qs, int segLen, uint32_t lut, int s)
+{
+	int hd = __shfl_up((int)Hs[segLen - 1], 1, 16);
+	if (s == 0) hd = 0;
+	int f = 0, cmax = 0;
+	const int nfull = segLen & ~3;
+	for (int j = 0; j < nfull; j += 4) {
+		const uint32_t hw = *reinterpret_cast<const uint32_t*>(Hs + j);
+		const uint32_t ew = *reinterpret_cast<const uint32_t*>(Es + j);
+		const uint32_t qw = *reinterpret_cast<const uint32_t*>(Qs + j);
+		uint32_t hn = 0, en = 0;
+#pragma unroll
+		for (int b = 0; b < 4; b++) {
+			const int qc4 = (qw >> (8 * b)) & 0xff;
+			const int p = (lut >> qc4) & 0xf;
+			int e = (ew >> (8 * b)) & 0xff;
+			const int hold = (hw >> (8 * b)) & 0xff;
+			int h = hd + p - BIAS;
+			h = min(h, 255 - BIAS);              // adds_epu8 saturation, then subs_epu8(bias)
+			h = max(h, e);
+			h = max(h, f);                       // e,f >= 0 => h >= 0
+			cmax = max(cmax, h);
+			hn |= (uint32_t)h << (8 * b);
+			const int ho = h - GAP_OPEN;
+			e = max(max(e - GAP_EXT, ho), 0);
+			f = max(max(f - GAP_EXT, ho), 0);
+			en |= (uint32_t)e << (8 * b);
+			hd = hold;
+		}
+		*reinterpret_cast<uint32_t*>(Hs + j) = hn;
+		*reinterpret_cast<uint32_t*>(Es + j) = en;
+	}
+	for (int j = nfull; j < segLen; j++) {
+		const int p = (lut >> Qs[j]) & 0xf;
+		int e = Es[j];
+		const int hold = Hs[j];
+		int h = hd + p - BIAS;
+		h = min(h, 255 - BIAS);
+		h = max(h, e);
+		h = max(h, f);
+		cmax = max(cmax, h);
+		Hs[j] = (uint8_t)h;
+		const int ho = h - GAP_OPEN;
+		e = max(max(e - GAP_EXT, ho), 0);
+		f = max(max(f - GAP_EXT, ho), 0);
+		Es[j] = (uint8_t)e;
+		hd = hold;
+	}
+	bool go = true;
+	for (int k = 0; k < 16 && go; k++) {
+		const int fs = __shfl_up(f, 1, 16);
+		f = (s == 0) ? 0 : fs;
+		for (int j = 0; j < segLen; j++) {
+			int h = Hs[j];
+			h = max(h, f);
+			cmax = max(cmax, h);
+			Hs[j] = (uint8_t)h;
+			const int ho = max(h - GAP_OPEN, 0);
+			f = max(f - GAP_EXT, 0);
+			const bool c = QUIRK ? ((int)(int8_t)f > (int)(int8_t)ho) : (f > ho);
+			if (!group_any16(c)) { go = false; break; }
+		}
+	}
+	return cmax;
+}
+
+// One column of the 16-bit kernel (8 stripes; lanes 8..15 of the group idle with part == false).
+// (sswNew.cpp:963-1001 / stats.h:555-598)
+__device__ __forceinline__ int column_word(uint16_t* Hs, uint16_t* Es, const uint8_t* Qs, int segLen, uint32_t lut, int s, bool part)
+{
+	int hd = __shfl_up((int)(int16_t)Hs[segLen - 1], 1, 16);
+	if (s == 0) hd = 0;
+	int f = 0, cmax = 0;
+	for (int j = 0; j < segLen; j++) {
+		const int p = (int)((lut >> Qs[j]) & 0xf) - BIAS;
+		int e = (int16_t)Es[j];
+		const int hold = (int16_t)Hs[j];
+		int h = min(hd + p, 32767);               // adds_epi16
+		h = max(h, e);
+		h = max(h, f);
+		cmax = max(cmax, h);
+		Hs[j] = (uint16_t)h;
+		const int ho = max(h - GAP_OPEN, 0);       // subs_epu16
+		e = max(max(e - GAP_EXT, 0), ho);
+		f = max(max(f - GAP_EXT, 0), ho);
+		Es[j] = (uint16_t)e;
+		hd = hold;
+	}
+	bool go = true;
+	for (int k = 0; k < 8 && go; k++) {
+		const int fs = __shfl_up(f, 1, 16);
+		f = (s == 0) ? 0 : fs;
+		for (int j = 0; j < segLen; j++) {
+			int h = (int16_t)Hs[j];
+			h = max(h, f);
+			cmax = max(cmax, h);
+			Hs[j] = (uint16_t)h;
+			const int ho = max(h - GAP_OPEN, 0);
+			f = max(f - GAP_EXT, 0);
+			if (!group_any16(part && f > ho)) { go = false; break; }
+		}
+	}
+	return part ? cmax : 0;
+}
+
+template <int MODE, bool WORD, bool QUIRK>
+__global__ void __launch_bounds__(64) k_striped(StripedArgs a)
+{
+	extern __shared__ __align__(16) uint8_t lds[];
+	using HT = typename std::conditional<WORD, uint16_t, uint8_t>::type;
+	constexpr int P = WORD ? 8 : 16;
+	const int g = threadIdx.x >> 4;
+	const int s = threadIdx.x & 15;
+	const int S4 = a.s4;
+	const size_t gbytes = (size_t)(WORD ? 80 : 48) * S4;
+	uint8_t* base = lds + g * gbytes;
+	HT* Hs = reinterpret_cast<HT*>(base) + (size_t)s * S4;
+	HT* Es = reinterpret_cast<HT*>(base) + (size_t)16 * S4 + (size_t)s * S4;
+	uint8_t* Qs = base + (size_t)(WORD ? 64 : 32) * S4 + (size_t)s * S4;
+	const bool part = s < P;
+	const uint32_t l0 = a.lut.row[0], l1 = a.lut.row[1], l2 = a.lut.row[2], l3 = a.lut.row[3], l4 = a.lut.row[4];
+
+	int phase = -1;          // -1: fetch a problem; 0: forward pass; 1: reverse pass (MODE_ALIGN)
+	int pi = 0, unit = 0, t0 = 0, refLen = 0, qlen = 0, dir = 0, terminate = 0, segLen = 1;
+	int ci = 0, maxv = 0, end_ref = 0, end_read = 0, tchunk = CODE_N;
+	int64_t tbase = 0;
+	bool overflow = false, setup = false, qrev = false;
+	AlignEnds res;
+	res.score_fwd = res.ref_end = res.read_end = res.score_rev = res.ref_begin = res.read_begin = 0;
+
+	for (;;) {
+		if (phase < 0) {
+			int idx = 0;
+			if (s == 0) idx = (int)atomicAdd(a.counter, 1u);
+			idx = __shfl(idx, 0, 16);
+			if (idx >= a.nprob) break;
+			pi = idx;
+			const StripedProb pb = a.probs[idx];
+			tbase = pb.tbase; t0 = pb.t0; refLen = pb.ref_len; qlen = pb.q_len; unit = pb.unit;
+			dir = 0; qrev = false; terminate = WORD ? 65535 : 255;
+			phase = 0; setup = true;
+			res.score_fwd = res.ref_end = res.read_end = res.score_rev = res.ref_begin = res.read_begin = 0;
+		}
+		if (setup) {
+			// stripe geometry of this pass: segLen = ceil(qlen / P) (sswNew.cpp:279, 911)
+			segLen = (qlen + P - 1) / P;
+			for (int j = 0; j < segLen; j++) {
+				const int row = s * segLen + j;
+				int code = CODE_PAD;                 // pad rows score 0 (sswNew.cpp:195, 690): Q3
+				if (part && row < qlen) code = a.qcodes[qrev ? (qlen - 1 - row) : row];
+				Qs[j] = (uint8_t)(code * 4);
+				Hs[j] = 0;
+				Es[j] = 0;
+			}
+			ci = 0; maxv = 0; overflow = false;
+			end_ref = WORD ? 0 : -1;                 // sswNew.cpp:278 vs :910
+			end_read = qlen - 1;
+			setup = false;
+		}
+		bool stop = (refLen <= 0);
+		if (!stop) {
+			const int i = dir ? (refLen - 1 - ci) : ci;          // window coordinate of this column
+			if ((ci & 15) == 0) {
+				const int cc = ci + s;
+				const int ii = dir ? (refLen - 1 - cc) : cc;
+				tchunk = (cc < refLen) ? (int)a.tcodes[tbase + t0 + ii] : CODE_N;
+			}
+			const int t = __shfl(tchunk, ci & 15, 16);
+			const uint32_t lut = t == 0 ? l0 : t == 1 ? l1 : t == 2 ? l2 : t == 3 ? l3 : l4;
+			int cmax;
+			if constexpr (WORD) cmax = column_word(Hs, Es, Qs, segLen, lut, s, part);
+			else cmax = column_byte<QUIRK>(Hs, Es, Qs, segLen, lut, s);
+			const int colmax = group_max16(cmax);
+			if (colmax > maxv) {
+				maxv = colmax;
+				if (!WORD && maxv + BIAS >= 255) { overflow = true; stop = true; }   // sswNew.cpp:386 / stats.h:729
+				else {
+					end_ref = i;
+					if constexpr (MODE == MODE_ALIGN) {
+						// smallest row whose stored H equals the new maximum (sswNew.cpp:621-629)
+						int best = 0x7fffffff;
+						if (part) {
+							for (int j = 0; j < segLen; j++) {
+								if ((int)Hs[j] == colmax) { best = s * segLen + j; break; }
+							}
+						}
+						best = group_min16(best);
+						end_read = best < qlen - 1 ? best : qlen - 1;
+					}
+				}
+			}
+			if (!stop) {
+				if constexpr (MODE == MODE_PRE) { if (s == 0) a.colmax[tbase + t0 + i] = (uint8_t)colmax; }
+				if (colmax == terminate) stop = true;
+			}
+			ci++;
+			if (ci >= refLen) stop = true;
+		}
+		if (stop) {
+			const int score = (!WORD && overflow) ? 255 : maxv;
+			if constexpr (MODE == MODE_PRE) {
+				if (overflow) {
+					// Q1: the overflowing column and everything after it stay 0 (calloc'd array, sswNew.cpp:282)
+					for (int c = (ci - 1) + s; c < refLen; c += 16) a.colmax[tbase + t0 + c] = 0;
+				}
+				if (s == 0) a.max_out[unit] = score;
+				phase = -1;
+			} else if constexpr (MODE == MODE_MAX1) {
+				if (s == 0) a.max_out[unit] = score;
+				phase = -1;
+			} else {
+				if (phase == 0) {
+					res.score_fwd = score;
+					res.ref_end = end_ref;
+					res.read_end = (maxv == 0) ? 0 : end_read;
+					if (score == 0 || (!WORD && score == 255) || end_ref < 0) {
+						if (s == 0) a.ends[pi] = res;          // nothing aligned, or needs the 16-bit re-run
+						phase = -1;
+					} else {
+						// reverse pass over the reversed query prefix, columns ref_end..0 (sswNew.cpp:1508-1516)
+						qlen = res.read_end + 1; refLen = res.ref_end + 1;
+						dir = 1; qrev = true; terminate = score;
+						phase = 1; setup = true;
+					}
+				} else {
+					res.score_rev = score;
+					res.ref_begin = end_ref;
+					res.read_begin = res.read_end - ((maxv == 0) ? 0 : end_read);
+					if (s == 0) a.ends[pi] = res;
+					phase = -1;
+				}
+			}
+		}
+	}
+}
+
+template <int MODE, bool WORD, bool QUIRK>
+static hipError_t launch_striped_t(const StripedLaunch& L, hipStream_t st)
+{
+	if (L.nprob <= 0) return hipSuccess;
+	constexpr int P = WORD ? 8 : 16;
+	int segLen = (L.max_qlen + P - 1) / P;
+	int s4 = (segLen + 3) & ~3;
+	if (((s4 / 4) & 1) == 0) s4 += 4;          // odd dword stride between stripes: conflict-free LDS rows
+	const size_t gbytes = (size_t)(WORD ? 80 : 48) * s4;
+	const size_t shmem = 4 * gbytes;
+	if (shmem > 160 * 1024) return hipErrorInvalidValue;   // query too long for the LDS-resident kernel
+	auto kern = k_striped<MODE, WORD, QUIRK>;
+	hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+	if (err != hipSuccess) return err;
+	err = hipMemsetAsync(L.counter, 0, sizeof(uint32_t), st);
+	if (err != hipSuccess) return err;
+	StripedArgs a;
+	a.tcodes = L.tcodes; a.qcodes = L.qcodes; a.probs = L.probs; a.nprob = L.nprob; a.counter = L.counter;
+	a.lut = L.lut; a.s4 = s4; a.colmax = L.colmax; a.max_out = L.max_out; a.ends = L.ends;
+	// enough 1-wave workgroups to fill the chip at the LDS-limited occupancy; the queue balances the rest
+	int per_cu = (int)((160 * 1024) / (shmem ? shmem : 1));
+	if (per_cu < 1) per_cu = 1;
+	if (per_cu > 16) per_cu = 16;
+	long blocks = (long)256 * per_cu;
+	const long need = ((long)L.nprob + 3) / 4;
+	if (blocks > need) blocks = need;
+	hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), shmem, st, a);
+	return hipGetLastError();
+}
+
+hipError_t launch_striped(StripedMode mode, bool word, bool quirk, const StripedLaunch& a, hipStream_t st)
+{
+	switch (mode) {
+	case MODE_PRE:
+		return launch_striped_t<MODE_PRE, false, true>(a, st);      // the 16-bit pre-align path is dead code (Q1)
+	case MODE_MAX1:
+		return word ? launch_striped_t<MODE_MAX1, true, false>(a, st) : launch_striped_t<MODE_MAX1, false, false>(a, st);
+	case MODE_ALIGN:
+		return word ? launch_striped_t<MODE_ALIGN, true, false>(a, st) : launch_striped_t<MODE_ALIGN, false, true>(a, st);
+	}
+	(void)quirk;
+	return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_hits: one wave per unit
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_hits(const uint8_t* __restrict__ colmax, const int32_t* __restrict__ unit_len,
+	const int32_t* __restrict__ stage1, int32_t tstride, uint32_t* __restrict__ hits, uint32_t hits_cap,
+	uint32_t* __restrict__ hits_total, int32_t* __restrict__ hit_off, int32_t* __restrict__ hit_cnt, int32_t* __restrict__ thr_out)
+{
+	const int unit = blockIdx.x;
+	const int lane = threadIdx.x;
+	const int n = unit_len[unit];
+	// minScore = (int)(calc_score_once(...) * 0.8)  -- double multiply, truncation (Fasim-LongTarget.cpp:413)
+	const int thr = (int)((double)stage1[unit] * 0.8);
+	const uint8_t* col = colmax + (int64_t)unit * tstride;
+	int cnt = 0;
+	for (int c0 = 0; c0 < n; c0 += 64) {
+		const int c = c0 + lane;
+		const bool hit = c < n && (int)col[c] > thr;
+		cnt += __popcll(__ballot(hit));
+	}
+	uint32_t off = 0;
+	if (lane == 0) off = atomicAdd(hits_total, (uint32_t)cnt);
+	off = __shfl(off, 0, 64);
+	if (lane == 0) { hit_off[unit] = (int32_t)off; hit_cnt[unit] = cnt; thr_out[unit] = thr; }
+	if ((uint64_t)off + (uint64_t)cnt > hits_cap) return;      // host sees hits_total > cap and retries
+	uint32_t w = off;
+	for (int c0 = 0; c0 < n; c0 += 64) {
+		const int c = c0 + lane;
+		const bool hit = c < n && (int)col[c] > thr;
+		const unsigned long long b = __ballot(hit);
+		if (hit) {
+			const int before = __popcll(b & ((1ull << lane) - 1ull));
+			hits[w + before] = ((uint32_t)c << 8) | (uint32_t)col[c];
+		}
+		w += __popcll(b);
+	}
+}
+
+hipError_t launch_hits(const uint8_t* colmax, const int32_t* unit_len, const int32_t* stage1, int32_t nunit,
+	int32_t tstride, uint32_t* hits, uint32_t hits_cap, uint32_t* hits_total, int32_t* hit_off, int32_t* hit_cnt,
+	int32_t* thr_out, hipStream_t st)
+{
+	if (nunit <= 0) return hipSuccess;
+	hipError_t err = hipMemsetAsync(hits_total, 0, sizeof(uint32_t), st);
+	if (err != hipSuccess) return err;
+	hipLaunchKernelGGL(k_hits, dim3(nunit), dim3(64), 0, st, colmax, unit_len, stage1, tstride, hits, hits_cap, hits_total,
+		hit_off, hit_cnt, thr_out);
+	return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_banded: banded_sw (sswNew.cpp:1071-1259), one thread per alignment, state in a private slice of
+// global scratch: [h_b | e_b | h_c : 3 * wmax int32][direction bytes ...]
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int sw_score(int a, int b) { return (a == b && a < 4) ? 5 : -4; }
+__device__ __forceinline__ uint32_t cigar_pack(int len, int op) { return ((uint32_t)len << 4) | (uint32_t)op; }   // op 0=M 1=I 2=D
+
+__global__ void __launch_bounds__(64) k_banded(const uint8_t* __restrict__ tcodes, const uint8_t* __restrict__ qcodes,
+	const BandProb* __restrict__ probs, int32_t nprob, uint8_t* __restrict__ scratch, BandOut* __restrict__ out)
+{
+	const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+	if (pi >= nprob) return;
+	const BandProb pb = probs[pi];
+	const uint8_t* ref = tcodes + pb.tbase;
+	const uint8_t* read = qcodes + pb.q_begin;
+	const int refLen = pb.ref_len, readLen = pb.read_len, score = pb.score;
+	uint8_t* my = scratch + pb.scratch_off;
+	const int cap = pb.scratch_cap;
+	// array slots sized for the widest band this scratch slice can hold
+	int wmax = cap / 64;
+	if (wmax > 4099) wmax = 4099;
+	if (wmax < 8) wmax = 8;
+	int32_t* h_b = reinterpret_cast<int32_t*>(my);
+	int32_t* e_b = h_b + wmax;
+	int32_t* h_c = e_b + wmax;
+	int8_t* direction = reinterpret_cast<int8_t*>(h_c + wmax);
+	const long dir_cap = (long)cap - (long)3 * wmax * 4;
+	BandOut* o = out + pi;
+
+	int band = (refLen > readLen ? refLen - readLen : readLen - refLen) + 1;
+	int maxv = 0, width = 0, width_d = 0;
+	do {
+		width = band * 2 + 3; width_d = band * 2 + 1;
+		if (width + 1 > wmax || (long)width_d * readLen * 3 + 3 > dir_cap) { o->status = 2; o->cigar_len = 0; return; }
+		for (int j = 1; j < width - 1; j++) h_b[j] = 0;
+		for (int i = 0; i < readLen; i++) {
+			int beg = 0, end = refLen - 1, u = 0;
+			if (i - band > beg) beg = i - band;
+			if (i + band < end) end = i + band;
+			const int edge = end + 1 < width - 1 ? end + 1 : width - 1;
+			int f = 0;
+			h_b[0] = 0; e_b[0] = 0; h_b[edge] = 0; e_b[edge] = 0; h_c[0] = 0;
+			int8_t* line = direction + (long)width_d * i * 3;
+			const int x = i - band > 0 ? i - band : 0;
+			const int xp = i - 1 - band > 0 ? i - 1 - band : 0;
+			const int rd = read[i];
+			for (int j = beg; j <= end; j++) {
+				u = j - x + 1;
+				const int e = j - xp + 1, b = j - x, d = j - xp;
+				int8_t* cell = line + (j - x) * 3;
+				int t1 = i == 0 ? -GAP_OPEN : h_b[e] - GAP_OPEN;
+				int t2 = i == 0 ? -GAP_EXT : e_b[e] - GAP_EXT;
+				const int ev = t1 > t2 ? t1 : t2;
+				e_b[u] = ev;
+				const int8_t de = t1 > t2 ? 3 : 2;
+				cell[0] = de;
+				t1 = h_c[b] - GAP_OPEN;
+				t2 = f - GAP_EXT;
+				f = t1 > t2 ? t1 : t2;
+				const int8_t df = t1 > t2 ? 5 : 4;
+				cell[1] = df;
+				const int e1 = ev > 0 ? ev : 0;
+				const int f1 = f > 0 ? f : 0;
+				t1 = e1 > f1 ? e1 : f1;
+				t2 = h_b[d] + sw_score(ref[j], rd);
+				const int hv = t1 > t2 ? t1 : t2;
+				h_c[u] = hv;
+				if (hv > maxv) maxv = hv;
+				cell[2] = (t1 <= t2) ? (int8_t)1 : (e1 > f1 ? de : df);
+			}
+			for (int j = 1; j <= u; j++) h_b[j] = h_c[j];
+		}
+		band *= 2;
+		// the reference would loop forever here; we stop and report undefined behaviour
+		if (maxv < score && band > 4 * (refLen + readLen) + 16) { o->status = 3; o->cigar_len = 0; return; }
+	} while (maxv < score);
+	band /= 2;
+
+	// trace back; the cigar is produced end-to-start, so fill the output from the back
+	uint32_t rc[MAX_CIGAR_DEV];
+	int l = 0;
+	int i = readLen - 1, j = refLen - 1, e = 0, state = 2;
+	int op = 0, prev_op = 0;     // 0=M 1=I 2=D
+	int status = 0;
+	while (i > 0) {
+		const int x = i - band > 0 ? i - band : 0;
+		int beg = 0, end = refLen - 1;
+		if (i - band > beg) beg = i - band;
+		if (i + band < end) end = i + band;
+		if (j < beg || j > end) { status = 3; break; }   // the reference reads memory it never wrote
+		const int8_t dv = direction[(long)width_d * i * 3 + (j - x) * 3 + state];
+		if (dv == 1) { --i; --j; state = 2; op = 0; }
+		else if (dv == 2) { --i; state = 0; op = 1; }
+		else if (dv == 3) { --i; state = 2; op = 1; }
+		else if (dv == 4) { --j; state = 1; op = 2; }
+		else if (dv == 5) { --j; state = 2; op = 2; }
+		else { status = 1; break; }
+		if (op == prev_op) ++e;
+		else {
+			if (l >= MAX_CIGAR_DEV) { status = 2; break; }
+			rc[l++] = cigar_pack(e, prev_op);
+			prev_op = op; e = 1;
+		}
+	}
+	if (status == 0) {
+		if (op == 0) {
+			if (l >= MAX_CIGAR_DEV) status = 2; else rc[l++] = cigar_pack(e + 1, 0);
+		} else {
+			if (l + 2 > MAX_CIGAR_DEV) status = 2; else { rc[l++] = cigar_pack(e, op); rc[l++] = cigar_pack(1, 0); }
+		}
+	}
+	o->status = status;
+	if (status != 0) { o->cigar_len = 0; return; }
+	o->cigar_len = l;
+	for (int k = 0; k < l; k++) o->cigar[k] = rc[l - 1 - k];
+}
+
+hipError_t launch_banded(const uint8_t* tcodes, const uint8_t* qcodes, const BandProb* probs, int32_t nprob,
+	uint8_t* scratch, BandOut* out, hipStream_t st)
+{
+	if (nprob <= 0) return hipSuccess;
+	hipLaunchKernelGGL(k_banded, dim3((nprob + 63) / 64), dim3(64), 0, st, tcodes, qcodes, probs, nprob, scratch, out);
+	return hipGetLastError();
+}
+
+} // namespace fasim

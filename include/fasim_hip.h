@@ -1,0 +1,129 @@
+/* include/fasim_hip.h -- C-ABI of libfasim_hip.so: the MI355X (gfx950) drop-in for the striped
+ * Smith-Waterman hot path of Fasim-LongTarget.
+ *
+ * The reference has no plugin registry; its native boundary for this path is the extern "C" block of
+ * ssw.h (ssw.h:19-197) plus, one level up, calc_score_once() (stats.h:879) and fastSIM() (fastsim.h:158)
+ * called from LongTarget() (Fasim-LongTarget.cpp:379-598).  Each entry point below names what it replaces.
+ * Plain pointers and sizes only; all pointers are HOST pointers unless the name says `_dev`.
+ * Every function returns 0 on success or a negative FASIM_E_* code; fasim_last_error() gives the text.
+ * There is NO CPU fallback behind this ABI: without a usable HIP device fasim_engine_create() fails.
+ */
+#ifndef FASIM_HIP_H
+#define FASIM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FASIM_OK            0
+#define FASIM_E_NODEVICE   -1   /* no HIP device / HIP runtime error at init                      */
+#define FASIM_E_ARG        -2   /* bad argument (null, empty query, letters outside ACGTUN, ...)   */
+#define FASIM_E_HIP        -3   /* HIP runtime error (message has the hipError string)             */
+#define FASIM_E_OVERFLOW   -4   /* a score left the 16-bit range the path computes in              */
+#define FASIM_E_UNSUPPORTED -5  /* input hits behaviour the reference leaves undefined (see DESIGN) */
+#define FASIM_E_NOMEM      -6
+
+typedef struct fasim_engine fasim_engine;
+
+/* Defaults of initEnv() (Fasim-LongTarget.cpp:284-303); field meaning = struct para (fastsim.h:22-45). */
+typedef struct fasim_params {
+	int32_t rule;            /* -r   0 = all rules                         */
+	int32_t cutLength;       /* -c   5000                                  */
+	int32_t strand;          /* -t   0 both, 1 parallel only, -1 anti only */
+	int32_t overlapLength;   /* -o   100                                   */
+	int32_t ntMin;           /* -ni  20                                    */
+	int32_t ntMax;           /* -na  100000                                */
+	float   scoreMin;        /*      0                                     */
+	float   minIdentity;     /* -i   60   (parsed with atoi by the CLI)    */
+	float   minStability;    /* -S   1    (parsed with atoi by the CLI)    */
+	int32_t penaltyT;        /* -pt  -1000                                 */
+	int32_t penaltyC;        /* -pc  0                                     */
+	int32_t cDistance;       /* -ds  15                                    */
+	int32_t cLength;         /* -lg  50                                    */
+} fasim_params;
+
+void fasim_params_default(fasim_params* p);
+
+/* ---- engine ---------------------------------------------------------------------------------- */
+int  fasim_engine_create(int device, fasim_engine** out);
+void fasim_engine_destroy(fasim_engine* e);
+const char* fasim_last_error(const fasim_engine* e);   /* e may be NULL: last global error */
+
+/* Replaces ssw_init()/init_destroy() (ssw.h:78,83) and init_work() (stats.h:386): the lncRNA is
+ * encoded once and stays resident on the device (the reference rebuilds its profile on every call). */
+int fasim_set_query(fasim_engine* e, const char* rna, int32_t len);
+
+/* ---- single-problem drop-ins of the native kernels (each launches the HIP path) --------------- */
+/* calc_score_once() (stats.h:879-956): exact max local score of the query vs `target`.            */
+int fasim_calc_score_once(fasim_engine* e, const char* target, int32_t n, int32_t* score);
+/* ssw_pre_align() (ssw.h:128, sswNew.cpp:1309) behind Aligner::preAlign's base translation
+ * (ssw_cpp.cpp:394-415): out_cols[n] = per-column maxima incl. the reference's Q1/Q2/Q3 behaviour. */
+int fasim_ssw_pre_align(fasim_engine* e, const char* target, int32_t n, int32_t* out_cols);
+/* peak picking of Aligner::preAlign (ssw_cpp.cpp:427-572) on a column-max array (host logic).     */
+int fasim_pick_candidates(const int32_t* cols, int32_t n, int32_t threshold,
+                          int32_t* out_score, int32_t* out_pos, int32_t cap, int32_t* count);
+/* ssw_align() (ssw.h:118, sswNew.cpp:1446) behind Aligner::Align (ssw_cpp.cpp:599-643).           */
+typedef struct fasim_alignment {
+	int32_t sw_score, ref_begin, ref_end, query_begin, query_end;
+	int32_t cigar_len;                 /* number of BAM-encoded ops in cigar[]                      */
+	uint32_t cigar[256];               /* (len<<4)|op, op 0=M 1=I 2=D (ssw.h:174)                   */
+} fasim_alignment;
+int fasim_ssw_align(fasim_engine* e, const char* window, int32_t n, fasim_alignment* out);
+/* batched forms (the shapes the engine uses internally): nprob problems, targets concatenated      */
+int fasim_pre_align_batch(fasim_engine* e, const char* targets, const int64_t* offsets, const int32_t* lens,
+                          int32_t nprob, int32_t* out_cols /* concatenated like targets */, int32_t* out_stage1);
+int fasim_align_batch(fasim_engine* e, const char* windows, const int64_t* offsets, const int32_t* lens,
+                      int32_t nprob, fasim_alignment* out);
+/* transferString()/reverseSeq()/complement() (rules.h:59-318) for encoding enc in [0,48), canonical
+ * execution order of LongTarget(): target[n] and src[n] (src is NUL-padded if letters were dropped). */
+int fasim_encode_unit(const char* seg, int32_t n, int32_t enc, char* target, char* src);
+
+/* ---- the batched body of LongTarget() (Fasim-LongTarget.cpp:379-598) -------------------------- */
+/* One record per triplex that survives fastSIM()'s own filter and LongTarget()'s tail filter, in the
+ * reference's order (segment, encoding, fastSIM rank).  Strings live in `pool` (NUL-terminated).   */
+typedef struct fasim_triplex {
+	int32_t stari, endi, starj, endj, strand, reverse, rule, nt;
+	float   score, identity, tri_score;
+	int32_t seg, enc;                   /* provenance: segment index, encoding index                 */
+	int32_t reserved;
+	int64_t tfo_off, tts_off;           /* offsets of stri_align / strj_align in pool                */
+} fasim_triplex;
+
+typedef struct fasim_scan_stats {
+	int64_t segments, segments_skipped, units;
+	int64_t candidates, align_calls, align_word_reruns, stage2_overflow_units, stage1_word_reruns;
+	int64_t logical_cells;              /* m * sum(len(segment)) * n_enc                  */
+	double  t_total_s, t_stage1_s, t_stage2_s, t_stage3_s, t_host_s;
+} fasim_scan_stats;
+
+typedef struct fasim_result {
+	fasim_triplex* recs; int64_t count;
+	char* pool; int64_t pool_len;
+	fasim_scan_stats stats;
+} fasim_result;
+
+/* Scans segments [seg_first, seg_first+seg_count) of `dna` (whole sequence of ONE FASTA record, host
+ * memory, upper-case ACGTN).  Coordinates in the records are relative to the whole `dna` exactly as in
+ * the reference.  seg_count < 0 = all remaining.  Used unsharded (1 GPU) or per rank (multi-GPU).   */
+int fasim_scan(fasim_engine* e, const char* dna, int64_t dna_len, int64_t seg_first, int64_t seg_count,
+               const fasim_params* p, fasim_result** out);
+void fasim_result_free(fasim_result* r);
+int64_t fasim_segment_count(int64_t dna_len, const fasim_params* p);   /* cutSequence(): fastsim.h:71 */
+
+/* ---- host tail: main() coordinates + cluster_triplex() + printResult() ------------------------- */
+/* (Fasim-LongTarget.cpp:141-149, 600-691, 797-829).  Takes the concatenation of all shards' records
+ * in canonical order and returns the bytes of the -TFOsorted file (malloc'd; free with fasim_free).  */
+int fasim_tfosorted(const fasim_triplex* recs, int64_t count, const char* pool, int64_t pool_len,
+                    const char* chr, int64_t start_genome, const fasim_params* p,
+                    char** text, int64_t* text_len);
+void fasim_free(void* p);
+
+/* deterministic synthetic DNA (splitmix64, 2 bits/base; same stream as tools/synth.py) */
+void fasim_synth_dna(char* out, int64_t n, uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

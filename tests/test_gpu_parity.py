@@ -1,0 +1,176 @@
+"""Parity of the HIP path (through the C-ABI) against the reference fixtures and the oracle.  GPU only."""
+import os
+import subprocess
+
+import pytest
+
+import helpers
+import synth
+import __graft_entry__ as entry
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mod():
+    if not os.path.exists(os.path.join(entry.PKG_DIR, "libfasim_hip.so")):
+        entry.build()
+    return entry.load()
+
+
+@pytest.fixture(scope="module")
+def engine(mod):
+    e = mod.Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def h19(golden_dir):
+    return synth.read_fasta(os.path.join(golden_dir, "H19.fa"))[1]
+
+
+def test_raw_kernels_against_reference_vectors(mod, engine, golden_dir):
+    """S = calc_score_once, P = ssw_pre_align, A = ssw_align on the reference's own outputs (batch.rsp)."""
+    reqs = open(os.path.join(golden_dir, "batch.req")).read().splitlines()
+    rsps = open(os.path.join(golden_dir, "batch.rsp")).read().splitlines()
+    by_query = {}
+    for rq, rs in zip(reqs, rsps):
+        f = rq.split(" ")
+        by_query.setdefault(f[1], []).append((f, rs.split(" ")))
+    checked = {"S": 0, "P": 0, "A": 0}
+    for q, items in by_query.items():
+        engine.set_query(q.encode())
+        targets = [f[2].encode() for f, _ in items if f[0] in "SP"]
+        if targets:
+            uniq = sorted(set(targets))
+            cols, s1 = engine.pre_align_batch(uniq)
+            cmap = dict(zip(uniq, cols))
+            smap = dict(zip(uniq, s1))
+        wins = [f[2].encode() for f, _ in items if f[0] == "A"]
+        amap = dict(zip(wins, engine.align_batch(wins))) if wins else {}
+        for f, g in items:
+            t = f[2].encode()
+            if f[0] == "S":
+                assert smap[t] == int(g[1]), ("S", q[:40], f[2][:40])
+            elif f[0] == "P":
+                assert cmap[t] == [int(x) for x in g[2:]], ("P", q[:40], f[2][:40])
+            elif f[0] == "A":
+                a = amap[t]
+                exp = tuple(int(x) for x in g[1:6])
+                if exp[0] == 0:
+                    assert a.sw_score == 0
+                else:
+                    got = (a.sw_score, a.ref_begin, a.ref_end, a.query_begin, a.query_end)
+                    assert got == exp and (a.cigar_string() or "*") == g[6], ("A", q[:40], f[2][:40], got, exp)
+            else:
+                continue
+            checked[f[0]] += 1
+    assert min(checked.values()) >= 50, checked
+
+
+def test_single_call_dropins(engine, h19, oracle_build):
+    o = helpers.Oracle(oracle_build)
+    engine.set_query(h19)
+    for seed, n in ((1, 1), (2, 17), (3, 300), (4, 1234)):
+        t = synth.random_dna(n, seed)
+        assert engine.calc_score_once(t) == o.stage1_max(h19, t)
+        assert engine.ssw_pre_align(t) == o.pre_align(h19, t)
+    w = synth.random_dna(120, 5)
+    a = engine.ssw_align(w)
+    five, cig = o.align(h19, w)
+    assert (a.sw_score, a.ref_begin, a.ref_end, a.query_begin, a.query_end) == five and a.cigar_string() == cig
+
+
+def _expected_triplexes(units):
+    exp = []
+    for u in units:
+        for x in u["triplexes"]:
+            f = list(x)
+            exp.append((int(f[0]), int(f[1]), int(f[2]), int(f[3]), int(f[4]), int(f[5]), int(f[6]), int(f[7]), int(f[8]),
+                        int(f[9], 16), int(f[10], 16), f[11].encode(), f[12].encode(), u["seg"], u["enc"]))
+    return exp
+
+
+@pytest.mark.parametrize("scan_name,dna_name", [("demo.scan.gz", "testDNA.fa"), ("planted40k.scan.gz", "planted40k.fa")])
+def test_scan_records_match_reference_fastsim(mod, engine, h19, golden_dir, scan_name, dna_name):
+    """Every triplex the reference's fastSIM() emits, unit by unit, bit for bit (identity/stability as float bits)."""
+    _, dna = synth.read_fasta(os.path.join(golden_dir, dna_name))
+    _, units = helpers.parse_scan(helpers.gunzip(os.path.join(golden_dir, scan_name)))
+    engine.set_query(h19)
+    res = engine.scan(dna, mod.default_params(cLength=20))     # cLength == ntMin: LongTarget's tail filter == fastSIM's
+    assert res.triplexes() == _expected_triplexes(units)
+    assert res.stats["units"] == len(units)
+    assert res.stats["candidates"] == sum(u["ncand"] for u in units)
+
+
+@pytest.mark.parametrize("name,dna_name,kw", [
+    ("demo_lg40.TFOsorted", "testDNA.fa", dict(cLength=40)),
+    ("demo_default.TFOsorted", "testDNA.fa", dict()),
+    ("demo_t1_r3.TFOsorted", "testDNA.fa", dict(cLength=30, strand=1, rule=3)),
+    ("planted40k.TFOsorted", "planted40k.fa", dict(cLength=40)),
+])
+def test_tfosorted_identical(mod, engine, h19, golden_dir, name, dna_name, kw):
+    hdr, dna = synth.read_fasta(os.path.join(golden_dir, dna_name))
+    _, chro, start = mod.parse_dna_header(hdr)
+    engine.set_query(h19)
+    p = mod.default_params(**kw)
+    res = engine.scan(dna, p)
+    assert mod.tfosorted(res, chro, start, p) == open(os.path.join(golden_dir, name), "rb").read()
+
+
+def test_rnd30k_tfosorted_and_sharding(mod, engine, h19, golden_dir):
+    dna = synth.random_dna(30000, 12345)
+    engine.set_query(h19)
+    p = mod.default_params(cLength=40)
+    whole = engine.scan(dna, p)
+    gold = open(os.path.join(golden_dir, "rnd30k.TFOsorted"), "rb").read()
+    assert mod.tfosorted(whole, "chrS", 1, p) == gold
+    # the same scan as 3 contiguous shards (what 3 ranks would do), merged in rank order
+    nseg = mod.segment_count(len(dna), p)
+    cuts = [0, nseg // 3, 2 * nseg // 3, nseg]
+    parts = [engine.scan(dna, p, cuts[i], cuts[i + 1] - cuts[i]) for i in range(3)]
+    merged = mod.merge_results(parts)
+    assert merged.recs == whole.recs and merged.pool == whole.pool
+    assert mod.tfosorted(merged, "chrS", 1, p) == gold
+
+
+def test_cli_driver_writes_identical_file(golden_dir, tmp_path):
+    exe = os.path.join(entry.PKG_DIR, "fasim")
+    for f in ("H19.fa", "testDNA.fa"):
+        (tmp_path / f).write_bytes(open(os.path.join(golden_dir, f), "rb").read())
+    (tmp_path / "out").mkdir()
+    subprocess.run([exe, "-f1", "testDNA.fa", "-f2", "H19.fa", "-O", "out/", "-lg", "40"], cwd=tmp_path, check=True,
+                   stdout=subprocess.DEVNULL)
+    got = (tmp_path / "out" / "hg19-H19-testDNA-TFOsorted").read_bytes()
+    assert got == open(os.path.join(golden_dir, "demo_lg40.TFOsorted"), "rb").read()
+
+
+def test_live_reference_probe_random_vectors(engine, oracle_build):
+    """If the compiled reference travelled with the repo (oracle/_ref), compare fresh random vectors too."""
+    if not helpers.have_ref_probe():
+        pytest.skip("oracle/_ref/ref_probe not present")
+    rng = synth._Rng(424242)
+    q = synth.random_rna(900 + rng.below(50), 7).decode()
+    engine.set_query(q.encode())
+    reqs, targets, wins = [], [], []
+    for k in range(40):
+        t = synth.planted_dna(300 + rng.below(900), 1000 + k, q.encode(), every=150, max_len=120).decode()
+        targets.append(t.encode())
+        reqs += [f"S {q} {t}", f"P {q} {t}"]
+        w = t[:60 + rng.below(130)]
+        wins.append(w.encode())
+        reqs.append(f"A {q} {w}")
+    rsp = helpers.ref_batch(reqs)
+    cols, s1 = engine.pre_align_batch(targets)
+    als = engine.align_batch(wins)
+    for k in range(40):
+        assert s1[k] == int(rsp[3 * k].split(" ")[1])
+        assert cols[k] == [int(x) for x in rsp[3 * k + 1].split(" ")[2:]]
+        g = rsp[3 * k + 2].split(" ")
+        a = als[k]
+        if int(g[1]) == 0:
+            assert a.sw_score == 0
+        else:
+            assert (a.sw_score, a.ref_begin, a.ref_end, a.query_begin, a.query_end) == tuple(int(x) for x in g[1:6])
+            assert (a.cigar_string() or "*") == g[6]
