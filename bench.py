@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the triplex-scan hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): H19 (2 812 nt, tests/golden/H19.fa) x synthetic uniform-random DNA
+(splitmix64 seed 12345 + rank, `--dna-mb` million nt, default 50) with the reference's default parameters:
+10 205 segments x 48 rule encodings = 489 840 work units per 50 Mb.  One STEP = one complete pass of the hot
+path over that record: stage-1 max score, stage-2 column maxima, candidate picking, every window alignment
+with traceback, triplex records -- i.e. everything fasim_scan() does.  The DNA record is uploaded once before
+the timed region and stays resident in HBM.  With N ranks every rank scans its own record (weak scaling,
+no data-path collective) and the records are gathered to rank 0 over RCCL inside the timed region.
+
+Prints ONE JSON line (rank 0).  value = logical SW Gcells/s of the whole job =
+sum_ranks(m * sum(len(segment)) * 48) * K / max_rank(time) / 1e9   (SURVEY.md 8(d)).
+"""
+import argparse
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import __graft_entry__ as entry  # noqa: E402
+import synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
+VALU_PEAK_TOPS = 78.6           # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, one 32-bit integer op per lane per clock
+KERNEL_NAMES = ["k_striped<MAX1> (stage 1)", "k_striped<PRE> (stage 2)", "k_striped<ALIGN> (stage 3 fwd+rev)",
+                "k_banded (traceback)", "k_encode+k_hits"]
+
+
+def cpu_baseline(rna_path, m, sample_nt, seed):
+    """The reference's own SSE2 binary (oracle/_ref/fasim_ref, built from /root/reference by oracle/Makefile)
+    on the first `sample_nt` nt of the same synthetic record, 1 thread (the reference is single-threaded).
+    Falls back to the oracle port when the reference binary did not travel."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "fasim_ref")
+    dna = synth.random_dna(sample_nt, seed)
+    nseg_cells = sum(min(5000, sample_nt - s) for s in range(0, sample_nt, 4900))
+    cells = m * nseg_cells * 48
+    wd = tempfile.mkdtemp(prefix="fasim_cpu_")
+    try:
+        synth.write_fasta(os.path.join(wd, "sample.fa"), f"syn|chrS|1-{sample_nt}", dna)
+        shutil.copyfile(rna_path, os.path.join(wd, "H19.fa"))
+        os.makedirs(os.path.join(wd, "out"))
+        if os.access(ref, os.X_OK):
+            t0 = time.perf_counter()
+            subprocess.run([ref, "-f1", "sample.fa", "-f2", "H19.fa", "-O", "out/"], cwd=wd, check=True,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            dt = time.perf_counter() - t0
+            kind = "reference"
+        else:
+            subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"], check=True)
+            exe = os.path.join(ROOT, "oracle", "_build", "fasim_oracle")
+            t0 = time.perf_counter()
+            subprocess.run([exe, "tfosorted", "H19.fa", "sample.fa"], cwd=wd, check=True, stdout=subprocess.DEVNULL)
+            dt = time.perf_counter() - t0
+            kind = "port"
+    finally:
+        shutil.rmtree(wd, ignore_errors=True)
+    return {"value": round(cells / dt / 1e9, 4), "unit": "Gcells/s", "cores": 1, "kind": kind,
+            "sample": f"H19 x first {sample_nt} nt of the same synthetic record, default parameters, {dt:.1f} s wall",
+            "mbp_per_s": round(sample_nt / dt / 1e6, 5)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--dna-mb", type=float, default=50.0, help="million nt of synthetic DNA per rank (default 50)")
+    ap.add_argument("--cpu-sample-nt", type=int, default=250000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    mod = entry.load()
+    eng = mod.Engine(local)
+    rna_path = os.path.join(ROOT, "tests", "golden", "H19.fa")
+    _, rna = synth.read_fasta(rna_path)
+    eng.set_query(rna)
+    n = int(args.dna_mb * 1e6)
+    dna = mod.synth_dna(n, 12345 + rank)
+    eng.load_dna(dna)                      # resident in HBM before the timed region
+    p = mod.default_params()
+
+    def step():
+        res = eng.scan(None, p)
+        if world > 1:
+            # the path's one exchange step: gather the shard's records on rank 0 over RCCL
+            payload = torch.frombuffer(bytearray(res.recs + res.pool) or bytearray(1), dtype=torch.uint8).cuda()
+            sizes = [torch.zeros(2, dtype=torch.int64, device="cuda") for _ in range(world)]
+            dist.all_gather(sizes, torch.tensor([len(res.recs), len(res.pool)], dtype=torch.int64, device="cuda"))
+            mx = max(int(s.sum()) for s in sizes)
+            buf = torch.zeros(max(mx, 1), dtype=torch.uint8, device="cuda")
+            buf[: payload.numel()] = payload
+            gathered = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+            dist.gather(buf, gathered, dst=0)
+            if rank == 0:
+                parts = []
+                for s, g in zip(sizes, gathered):
+                    nr, npool = int(s[0]), int(s[1])
+                    b = g[: nr + npool].cpu().numpy().tobytes()
+                    parts.append(mod.ScanResult(b[:nr], b[nr:], {}))
+                merged = mod.merge_results(parts)
+                return res, merged.count
+        return res, res.count
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    agg = None
+    nrec = 0
+    for _ in range(args.steps):
+        res, nrec = step()
+        st = res.stats
+        if agg is None:
+            agg = {k: (list(v) if isinstance(v, list) else v) for k, v in st.items()}
+        else:
+            for k, v in st.items():
+                if isinstance(v, list):
+                    agg[k] = [a + b for a, b in zip(agg[k], v)]
+                else:
+                    agg[k] += v
+    sync()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    cells = torch.tensor([float(agg["logical_cells"])], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cells, op=dist.ReduceOp.SUM)
+    tmax = float(tmax.item())
+    total_cells = float(cells.item())
+
+    if rank == 0:
+        m = len(rna)
+        units_per_step = agg["units"] / args.steps
+        # dominant kernel by HIP-event time
+        kms = agg["kernel_ms"]
+        dom = max(range(5), key=lambda i: kms[i])
+        launches = max(1, agg["kernel_launches"][dom])
+        avg_ms = kms[dom] / launches
+        n_avg = agg["cells_stage2"] / max(1, agg["units"]) / m        # mean segment length
+        if dom == 0:
+            bytes_per_unit, units_dom = n_avg + 5 * m + 4, agg["units"] + agg["stage1_word_reruns"]
+            cells_dom = agg["cells_stage1"]
+        elif dom == 1:
+            bytes_per_unit, units_dom = 3 * n_avg + 5 * m, agg["units"]
+            cells_dom = agg["cells_stage2"]
+        else:
+            calls = max(1, agg["align_calls"])
+            bytes_per_unit, units_dom = agg["cells_stage3"] / m / calls + 5 * m + 24, calls
+            cells_dom = agg["cells_stage3"]
+        alg_bytes_per_launch = bytes_per_unit * units_dom / launches
+        achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "SW Gcells/s (logical, whole job: stage 1+2+3 of the triplex scan)",
+            "value": round(total_cells / tmax / 1e9, 3),
+            "unit": "Gcells/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(tmax / args.steps * 1e3, 2),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": f"H19 (2812 nt) x synthetic {args.dna_mb:g} Mb DNA per GPU (splitmix64 seed 12345+rank), "
+                                   "default parameters, 48 rule encodings, records gathered to rank 0",
+                       "units_per_step_per_gpu": int(units_per_step), "records_rank0": int(nrec)},
+            "mbp_per_s": round(n * world * args.steps / tmax / 1e6, 3),
+            "executed_gcells_per_s": round((agg["cells_stage1"] + agg["cells_stage2"] + agg["cells_stage3"]) / (tmax) / 1e9 * 1.0, 3),
+            "phase_wall_s": {k: round(agg[k], 3) for k in ("t_stage1_s", "t_stage2_s", "t_stage3_s", "t_host_s", "t_total_s")},
+            "kernel_ms": {KERNEL_NAMES[i]: round(kms[i], 2) for i in range(5)},
+            "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "avg_launch_ms": round(avg_ms, 3), "launches": int(launches),
+                         "algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
+                         "note": "integer DP is VALU-bound by construction; see valu"},
+            "valu": {"kernel": KERNEL_NAMES[dom], "gcells_per_s": round(cells_dom / (kms[dom] * 1e-3) / 1e9, 2),
+                     "ops_per_cell": 15, "achieved_tops": round(cells_dom * 15 / (kms[dom] * 1e-3) / 1e12, 3),
+                     "peak_tops": VALU_PEAK_TOPS,
+                     "frac": round(cells_dom * 15 / (kms[dom] * 1e-3) / 1e12 / VALU_PEAK_TOPS, 4)},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(rna_path, m, args.cpu_sample_nt, 12345)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -57,7 +57,9 @@ class ScanStats(C.Structure):
     _fields_ = [("segments", C.c_int64), ("segments_skipped", C.c_int64), ("units", C.c_int64), ("candidates", C.c_int64),
                 ("align_calls", C.c_int64), ("align_word_reruns", C.c_int64), ("stage2_overflow_units", C.c_int64),
                 ("stage1_word_reruns", C.c_int64), ("logical_cells", C.c_int64), ("t_total_s", C.c_double),
-                ("t_stage1_s", C.c_double), ("t_stage2_s", C.c_double), ("t_stage3_s", C.c_double), ("t_host_s", C.c_double)]
+                ("t_stage1_s", C.c_double), ("t_stage2_s", C.c_double), ("t_stage3_s", C.c_double), ("t_host_s", C.c_double),
+                ("kernel_ms", C.c_double * 5), ("kernel_launches", C.c_int64 * 5), ("cells_stage1", C.c_int64),
+                ("cells_stage2", C.c_int64), ("cells_stage3", C.c_int64)]
 
 
 class _Result(C.Structure):
@@ -67,7 +69,7 @@ class _Result(C.Structure):
 
 EXPORTS = ["fasim_params_default", "fasim_engine_create", "fasim_engine_destroy", "fasim_last_error", "fasim_set_query",
            "fasim_calc_score_once", "fasim_ssw_pre_align", "fasim_pick_candidates", "fasim_ssw_align", "fasim_pre_align_batch",
-           "fasim_align_batch", "fasim_encode_unit", "fasim_scan", "fasim_result_free", "fasim_segment_count",
+           "fasim_align_batch", "fasim_encode_unit", "fasim_scan", "fasim_load_dna", "fasim_result_free", "fasim_segment_count",
            "fasim_tfosorted", "fasim_free", "fasim_synth_dna"]
 
 _lib = None
@@ -101,6 +103,7 @@ def lib():
     L.fasim_encode_unit.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_char_p, C.c_char_p]
     L.fasim_scan.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(Params),
                              C.POINTER(C.POINTER(_Result))]
+    L.fasim_load_dna.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     L.fasim_result_free.argtypes = [C.POINTER(_Result)]
     L.fasim_result_free.restype = None
     L.fasim_segment_count.argtypes = [C.c_int64, C.POINTER(Params)]
@@ -244,15 +247,23 @@ class Engine:
         return list(out)
 
     # --- the LongTarget() body ----------------------------------------------------------------------
-    def scan(self, dna: bytes, params: Params | None = None, seg_first: int = 0, seg_count: int = -1) -> ScanResult:
+    def load_dna(self, dna: bytes):
+        """Upload one DNA record and keep it resident in HBM; scan(None, ...) then scans it without H2D copies."""
+        self._check(self._L.fasim_load_dna(self._h, dna, len(dna)))
+
+    def scan(self, dna: bytes | None, params: Params | None = None, seg_first: int = 0, seg_count: int = -1) -> ScanResult:
         p = params or default_params()
         res = C.POINTER(_Result)()
-        self._check(self._L.fasim_scan(self._h, dna, len(dna), seg_first, seg_count, C.byref(p), C.byref(res)))
+        self._check(self._L.fasim_scan(self._h, dna, len(dna) if dna is not None else 0, seg_first, seg_count, C.byref(p),
+                                       C.byref(res)))
         try:
             r = res.contents
             recs = C.string_at(r.recs, r.count * C.sizeof(Triplex)) if r.count else b""
             pool = C.string_at(r.pool, r.pool_len) if r.pool_len else b""
-            stats = {k: getattr(r.stats, k) for k, _ in ScanStats._fields_}
+            stats = {}
+            for k, _ in ScanStats._fields_:
+                v = getattr(r.stats, k)
+                stats[k] = list(v) if hasattr(v, "__len__") else v
         finally:
             self._L.fasim_result_free(res)
         return ScanResult(recs, pool, stats)

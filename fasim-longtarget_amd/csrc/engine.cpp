@@ -59,6 +59,15 @@ struct fasim_engine {
 	DevBuf q1, q2, enc_lut, counter, dna, seg_start, seg_len, enc_ids, tcodes, colmax, probs, max_out, unit_len,
 		stage1, hits, hits_total, hit_off, hit_cnt, thr, ends, bprobs, bout, scratch;
 	int host_threads = 1;
+	// resident DNA record (fasim_load_dna)
+	std::string dna_host;
+	DevBuf dna_res;
+	// HIP-event timing of kernel launches on `st`
+	struct Timed { hipEvent_t a, b; int family; };
+	std::vector<Timed> timed;
+	std::vector<hipEvent_t> ev_pool;
+	double kernel_ms[5] = { 0, 0, 0, 0, 0 };
+	int64_t kernel_launches[5] = { 0, 0, 0, 0, 0 };
 };
 
 namespace {
@@ -95,6 +104,30 @@ ScoreLut make_lut(bool stage1)
 		L.row[t] = w;
 	}
 	return L;
+}
+
+// ---- HIP-event timing ----------------------------------------------------------------------------
+hipEvent_t get_event(fasim_engine* E)
+{
+	if (!E->ev_pool.empty()) { hipEvent_t e = E->ev_pool.back(); E->ev_pool.pop_back(); return e; }
+	hipEvent_t e = nullptr;
+	if (hipEventCreate(&e) != hipSuccess) return nullptr;
+	return e;
+}
+struct TimedScope {
+	fasim_engine* E; hipEvent_t a = nullptr, b = nullptr; int family;
+	TimedScope(fasim_engine* e, int fam) : E(e), family(fam) { a = get_event(E); b = get_event(E); if (a) (void)hipEventRecord(a, E->st); }
+	~TimedScope() { if (a && b) { (void)hipEventRecord(b, E->st); E->timed.push_back({ a, b, family }); } }
+};
+// call after a stream synchronisation
+void drain_timed(fasim_engine* E)
+{
+	for (auto& t : E->timed) {
+		float ms = 0.0f;
+		if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) { E->kernel_ms[t.family] += ms; E->kernel_launches[t.family]++; }
+		E->ev_pool.push_back(t.a); E->ev_pool.push_back(t.b);
+	}
+	E->timed.clear();
 }
 
 // ---- a batch of units whose target codes are resident on the device ------------------------------
@@ -136,7 +169,11 @@ int run_striped(fasim_engine* E, StripedMode mode, bool word, const std::vector<
 	L.probs = E->probs.as<StripedProb>(); L.nprob = (int)probs.size(); L.counter = E->counter.as<uint32_t>();
 	L.lut = stage1 ? E->lut1 : E->lut2; L.max_qlen = max_qlen;
 	L.colmax = E->colmax.as<uint8_t>(); L.max_out = E->max_out.as<int32_t>(); L.ends = E->ends.as<AlignEnds>();
-	hipError_t he = launch_striped(mode, word, !stage1, L, E->st);
+	hipError_t he;
+	{
+		TimedScope ts(E, mode == MODE_MAX1 ? 0 : mode == MODE_PRE ? 1 : 2);
+		he = launch_striped(mode, word, !stage1, L, E->st);
+	}
 	if (he == hipErrorInvalidValue) return fail(E, FASIM_E_UNSUPPORTED, "query of %d nt does not fit the LDS-resident striped kernel", max_qlen);
 	if (he != hipSuccess) return fail(E, FASIM_E_HIP, "striped kernel launch failed: %s", hipGetErrorString(he));
 	return FASIM_OK;
@@ -243,8 +280,12 @@ int run_align(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>
 			HIPOK(E->bout.ensure(sizeof(BandOut) * cnt));
 			rc = upload(E, E->bprobs, cur.data(), sizeof(BandProb) * cnt);
 			if (rc) return rc;
-			hipError_t he = launch_banded(E->tcodes.as<uint8_t>(), E->q2.as<uint8_t>(), E->bprobs.as<BandProb>(), (int)cnt,
-				E->scratch.as<uint8_t>(), E->bout.as<BandOut>(), E->st);
+			hipError_t he;
+			{
+				TimedScope ts(E, 3);
+				he = launch_banded(E->tcodes.as<uint8_t>(), E->q2.as<uint8_t>(), E->bprobs.as<BandProb>(), (int)cnt,
+					E->scratch.as<uint8_t>(), E->bout.as<BandOut>(), E->st);
+			}
 			if (he != hipSuccess) return fail(E, FASIM_E_HIP, "banded kernel launch failed: %s", hipGetErrorString(he));
 			std::vector<BandOut> tmp(cnt);
 			HIPOK(hipMemcpyAsync(tmp.data(), E->bout.p, sizeof(BandOut) * cnt, hipMemcpyDeviceToHost, E->st));
@@ -335,7 +376,9 @@ void fasim_engine_destroy(fasim_engine* e)
 	(void)hipSetDevice(e->device);
 	DevBuf* bufs[] = { &e->q1, &e->q2, &e->enc_lut, &e->counter, &e->dna, &e->seg_start, &e->seg_len, &e->enc_ids, &e->tcodes,
 		&e->colmax, &e->probs, &e->max_out, &e->unit_len, &e->stage1, &e->hits, &e->hits_total, &e->hit_off, &e->hit_cnt, &e->thr,
-		&e->ends, &e->bprobs, &e->bout, &e->scratch };
+		&e->ends, &e->bprobs, &e->bout, &e->scratch, &e->dna_res };
+	for (auto& t : e->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+	for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
 	for (DevBuf* b : bufs) b->release();
 	if (e->st) (void)hipStreamDestroy(e->st);
 	delete e;
@@ -446,6 +489,18 @@ int fasim_encode_unit(const char* seg, int32_t n, int32_t enc, char* target, cha
 	return FASIM_OK;
 }
 
+int fasim_load_dna(fasim_engine* E, const char* dna, int64_t dna_len)
+{
+	if (!E) return fail(nullptr, FASIM_E_ARG, "null engine");
+	if (!dna || dna_len <= 0) return fail(E, FASIM_E_ARG, "empty DNA");
+	if (dna_len > 0x7fffffffll) return fail(E, FASIM_E_ARG, "one record is limited to 2^31-1 nt");
+	HIPOK(hipSetDevice(E->device));
+	E->dna_host.assign(dna, dna + dna_len);
+	int rc = upload(E, E->dna_res, dna, (size_t)dna_len);
+	if (rc) { E->dna_host.clear(); return rc; }
+	return FASIM_OK;
+}
+
 int64_t fasim_segment_count(int64_t dna_len, const fasim_params* p)
 {
 	// cutSequence (fastsim.h:71-90): pos += cut - overlap while pos < size
@@ -481,6 +536,11 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 	const fasim_params* pp, fasim_result** out)
 {
 	int rc = need_query(E); if (rc) return rc;
+	const bool resident = (dna == nullptr);
+	if (resident) {
+		if (E->dna_host.empty()) return fail(E, FASIM_E_ARG, "no resident DNA: call fasim_load_dna first");
+		dna = E->dna_host.data(); dna_len = (int64_t)E->dna_host.size();
+	}
 	if (!dna || dna_len <= 0 || !pp || !out) return fail(E, FASIM_E_ARG, "bad arguments");
 	const fasim_params p = *pp;
 	if (p.cutLength <= 0 || p.cutLength - p.overlapLength <= 0) return fail(E, FASIM_E_ARG, "cutLength/overlapLength invalid");
@@ -488,6 +548,8 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 	HIPOK(hipSetDevice(E->device));
 	const double t_begin = now_s();
 	fasim_scan_stats st; memset(&st, 0, sizeof st);
+	drain_timed(E);
+	for (int k = 0; k < 5; k++) { E->kernel_ms[k] = 0; E->kernel_launches[k] = 0; }
 
 	const int64_t nseg_all = fasim_segment_count(dna_len, &p);
 	if (seg_first < 0) seg_first = 0;
@@ -501,7 +563,9 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 		// the shard's DNA stays resident for the whole scan
 		const int64_t shard_lo = seg_first * step;
 		const int64_t shard_hi = std::min<int64_t>(dna_len, (seg_first + seg_count - 1) * step + p.cutLength);
-		rc = upload(E, E->dna, dna + shard_lo, (size_t)(shard_hi - shard_lo)); if (rc) return rc;
+		const uint8_t* dna_dev;
+		if (resident) dna_dev = E->dna_res.as<uint8_t>() + shard_lo;
+		else { rc = upload(E, E->dna, dna + shard_lo, (size_t)(shard_hi - shard_lo)); if (rc) return rc; dna_dev = E->dna.as<uint8_t>(); }
 		rc = upload(E, E->enc_ids, encs.data(), sizeof(int) * nenc); if (rc) return rc;
 
 		const int tstride = (p.cutLength + 15) & ~15;
@@ -527,12 +591,15 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 			UnitBatch B; B.nunit = nseg * nenc; B.tstride = tstride; B.unit_len.resize(B.nunit);
 			for (int s = 0; s < nseg; s++) for (int k = 0; k < nenc; k++) B.unit_len[s * nenc + k] = slen[s];
 			st.units += B.nunit;
+			for (int s = 0; s < nseg; s++) { st.cells_stage1 += (int64_t)E->m * slen[s] * nenc; st.cells_stage2 += (int64_t)E->m * slen[s] * nenc; }
 			rc = upload(E, E->seg_start, sstart.data(), sizeof(int32_t) * nseg); if (rc) return rc;
 			rc = upload(E, E->seg_len, slen.data(), sizeof(int32_t) * nseg); if (rc) return rc;
 			rc = upload(E, E->unit_len, B.unit_len.data(), sizeof(int32_t) * B.nunit); if (rc) return rc;
 			HIPOK(E->tcodes.ensure((size_t)B.nunit * tstride));
-			hipError_t he = launch_encode(E->dna.as<uint8_t>(), E->seg_start.as<int32_t>(), E->seg_len.as<int32_t>(), nseg,
-				E->enc_ids.as<int32_t>(), nenc, E->enc_lut.as<uint8_t>(), E->tcodes.as<uint8_t>(), tstride, E->st);
+			hipError_t he;
+			{ TimedScope ts(E, 4);
+			he = launch_encode(dna_dev, E->seg_start.as<int32_t>(), E->seg_len.as<int32_t>(), nseg,
+				E->enc_ids.as<int32_t>(), nenc, E->enc_lut.as<uint8_t>(), E->tcodes.as<uint8_t>(), tstride, E->st); }
 			if (he != hipSuccess) return fail(E, FASIM_E_HIP, "encode launch failed: %s", hipGetErrorString(he));
 
 			// ---- stage 1
@@ -552,9 +619,10 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 			size_t hits_cap = std::max<size_t>(E->hits.cap / 4, (size_t)B.nunit * 128);
 			for (;;) {
 				HIPOK(E->hits.ensure(hits_cap * sizeof(uint32_t)));
+				{ TimedScope ts(E, 4);
 				he = launch_hits(E->colmax.as<uint8_t>(), E->unit_len.as<int32_t>(), E->stage1.as<int32_t>(), B.nunit, tstride,
 					E->hits.as<uint32_t>(), (uint32_t)hits_cap, E->hits_total.as<uint32_t>(), E->hit_off.as<int32_t>(),
-					E->hit_cnt.as<int32_t>(), E->thr.as<int32_t>(), E->st);
+					E->hit_cnt.as<int32_t>(), E->thr.as<int32_t>(), E->st); }
 				if (he != hipSuccess) return fail(E, FASIM_E_HIP, "hits launch failed: %s", hipGetErrorString(he));
 				uint32_t total = 0;
 				HIPOK(hipMemcpyAsync(&total, E->hits_total.p, sizeof total, hipMemcpyDeviceToHost, E->st));
@@ -595,11 +663,13 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 				}
 				if (W.empty()) break;
 				st.align_calls += (int64_t)W.size();
+				for (const WindowProb& w : W) st.cells_stage3 += (int64_t)E->m * w.len;
 				std::vector<AlignResult> res;
 				rc = run_align(E, B, W, res, &st); if (rc) return rc;
 				for (size_t i = 0; i < who.size(); i++) {
 					CandState& x = cs[who[i]];
 					x.al = res[i];
+					if (x.al.sw_score > 0) st.cells_stage3 += (int64_t)(x.al.query_end + 1) * (x.al.ref_end - x.al.ref_begin + 1);   // reverse pass
 					if (x.al.sw_score >= x.c.score) { x.flag = 1; x.done = 1; continue; }                    // fastsim.h:218-221
 					if (x.al.sw_score > x.best.sw_score && x.al.ref_end == x.cut - 1) { x.best = x.al; x.bestcut = x.cut; x.flag = 2; }   // :222-235
 				}
@@ -666,6 +736,9 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 		r.tfo_off = (int64_t)off; memcpy(R->pool + off, t.tfo.c_str(), t.tfo.size() + 1); off += t.tfo.size() + 1;
 		r.tts_off = (int64_t)off; memcpy(R->pool + off, t.tts.c_str(), t.tts.size() + 1); off += t.tts.size() + 1;
 	}
+	(void)hipStreamSynchronize(E->st);
+	drain_timed(E);
+	for (int k = 0; k < 5; k++) { st.kernel_ms[k] = E->kernel_ms[k]; st.kernel_launches[k] = E->kernel_launches[k]; }
 	st.t_total_s = now_s() - t_begin;
 	R->stats = st;
 	*out = R;

@@ -95,7 +95,12 @@ typedef struct fasim_scan_stats {
 	int64_t segments, segments_skipped, units;
 	int64_t candidates, align_calls, align_word_reruns, stage2_overflow_units, stage1_word_reruns;
 	int64_t logical_cells;              /* m * sum(len(segment)) * n_enc                  */
-	double  t_total_s, t_stage1_s, t_stage2_s, t_stage3_s, t_host_s;
+	double  t_total_s, t_stage1_s, t_stage2_s, t_stage3_s, t_host_s;   /* host wall clock per phase       */
+	/* HIP-event time of the kernels, summed over launches on the engine's stream (index: 0 stage-1 striped,
+	 * 1 stage-2 striped, 2 stage-3 striped fwd+rev, 3 banded traceback, 4 encode+hits)                 */
+	double  kernel_ms[5];
+	int64_t kernel_launches[5];
+	int64_t cells_stage1, cells_stage2, cells_stage3;   /* DP cells actually executed (stage 3: fwd + rev)   */
 } fasim_scan_stats;
 
 typedef struct fasim_result {
@@ -109,6 +114,9 @@ typedef struct fasim_result {
  * the reference.  seg_count < 0 = all remaining.  Used unsharded (1 GPU) or per rank (multi-GPU).   */
 int fasim_scan(fasim_engine* e, const char* dna, int64_t dna_len, int64_t seg_first, int64_t seg_count,
                const fasim_params* p, fasim_result** out);
+/* Optional: upload a DNA record once and keep it resident in HBM (and a host copy for the string work);
+ * afterwards fasim_scan(e, NULL, 0, ...) scans the resident record without any H2D copy of the sequence. */
+int fasim_load_dna(fasim_engine* e, const char* dna, int64_t dna_len);
 void fasim_result_free(fasim_result* r);
 int64_t fasim_segment_count(int64_t dna_len, const fasim_params* p);   /* cutSequence(): fastsim.h:71 */
 
