@@ -33,8 +33,8 @@ import synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_TOPS = 78.6           # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, one 32-bit integer op per lane per clock
-KERNEL_NAMES = ["k_striped<MAX1> (stage 1)", "k_striped<PRE> (stage 2)", "k_striped<ALIGN> (stage 3 fwd+rev)",
-                "k_banded (traceback)", "k_encode+k_hits"]
+KERNEL_NAMES = ["k_scan (fused stage 1+2)", "k_striped (stage 1/2 hazard re-runs)", "stage-3 alignment kernels",
+                "traceback kernels", "k_encode + hit extraction"]
 
 
 def cpu_baseline(rna_path, m, sample_nt, seed):

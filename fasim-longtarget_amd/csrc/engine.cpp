@@ -57,7 +57,9 @@ struct fasim_engine {
 	int m = 0;
 	ScoreLut lut1, lut2;
 	DevBuf q1, q2, enc_lut, counter, dna, seg_start, seg_len, enc_ids, tcodes, colmax, probs, max_out, unit_len,
-		stage1, hits, hits_total, hit_off, hit_cnt, thr, ends, bprobs, bout, scratch;
+		stage1, hits, hits_total, hit_off, hit_cnt, thr, ends, bprobs, bout, scratch, colmax16, unit_ids, flags, stage1_in, hits2;
+	bool query_acgt = true;       // query holds only A,C,G,T: stage-1 and stage-2 scoring coincide on N-free segments
+	bool scan_v1 = false;         // FASIM_SCAN_V1=1: force the stripe-faithful kernels for stages 1 and 2
 	int host_threads = 1;
 	// resident DNA record (fasim_load_dna)
 	std::string dna_host;
@@ -171,7 +173,7 @@ int run_striped(fasim_engine* E, StripedMode mode, bool word, const std::vector<
 	L.colmax = E->colmax.as<uint8_t>(); L.max_out = E->max_out.as<int32_t>(); L.ends = E->ends.as<AlignEnds>();
 	hipError_t he;
 	{
-		TimedScope ts(E, mode == MODE_MAX1 ? 0 : mode == MODE_PRE ? 1 : 2);
+		TimedScope ts(E, mode == MODE_ALIGN ? 2 : 1);
 		he = launch_striped(mode, word, !stage1, L, E->st);
 	}
 	if (he == hipErrorInvalidValue) return fail(E, FASIM_E_UNSUPPORTED, "query of %d nt does not fit the LDS-resident striped kernel", max_qlen);
@@ -213,6 +215,120 @@ int run_stage2(fasim_engine* E, const UnitBatch& B)
 	HIPOK(E->colmax.ensure((size_t)B.nunit * B.tstride));
 	HIPOK(E->max_out.ensure(sizeof(int32_t) * B.nunit));
 	return run_striped(E, MODE_PRE, false, whole_unit_probs(B, E->m, nullptr), false, E->tcodes.as<uint8_t>(), E->m);
+}
+
+// ---- stages 1+2 through the fused systolic kernel (scan.hip) -----------------------------------------
+struct ScanOut {
+	std::vector<int32_t> stage1, thr, hit_off, hit_cnt, flags;
+	std::vector<uint32_t> hits;
+};
+
+void fill_scores(int8_t* sc, bool stage1)
+{
+	for (int t = 0; t < 5; t++) for (int q = 0; q < 5; q++)
+		sc[t * 5 + q] = (int8_t)(stage1 ? ((t == 4 || q == 4) ? -1 : (t == q ? 5 : -4)) : ((t == q && t < 4) ? 5 : -4));
+}
+
+// returns 1 when the query does not fit the kernel (caller falls back to the striped kernels)
+int run_scan_v2(fasim_engine* E, const UnitBatch& B, const std::vector<char>& unit_needs_stage1, ScanOut& out,
+	fasim_scan_stats* st)
+{
+	const int nu = B.nunit;
+	HIPOK(E->colmax16.ensure((size_t)nu * B.tstride * sizeof(uint16_t)));
+	std::vector<int32_t> ids(nu), sep;
+	for (int u = 0; u < nu; u++) { ids[u] = u; if (unit_needs_stage1[u]) sep.push_back(u); }
+	std::vector<int32_t> s1in(nu, -1);
+	int rc = upload(E, E->stage1_in, s1in.data(), sizeof(int32_t) * nu); if (rc) return rc;
+	ScanLaunch L;
+	L.tcodes = E->tcodes.as<uint8_t>(); L.unit_len = E->unit_len.as<int32_t>(); L.tstride = B.tstride;
+	L.counter = E->counter.as<uint32_t>(); L.m = E->m; L.colmax16 = E->colmax16.as<uint16_t>();
+	hipError_t he;
+	if (!sep.empty()) {
+		// units whose segment holds N (or every unit, when the query has letters outside ACGT): the stage-1
+		// alphabet differs (Q4), so the exact stage-1 maximum needs its own pass
+		rc = upload(E, E->unit_ids, sep.data(), sizeof(int32_t) * sep.size()); if (rc) return rc;
+		L.unit_ids = E->unit_ids.as<int32_t>(); L.nwork = (int)sep.size(); L.qcodes = E->q1.as<uint8_t>(); fill_scores(L.score, true);
+		{ TimedScope ts(E, 0); he = launch_scan(L, E->st); }
+		if (he == hipErrorInvalidValue) return 1;
+		if (he != hipSuccess) return fail(E, FASIM_E_HIP, "scan (stage-1 pass) launch failed: %s", hipGetErrorString(he));
+		he = launch_max16(E->colmax16.as<uint16_t>(), E->unit_ids.as<int32_t>(), (int)sep.size(), E->unit_len.as<int32_t>(),
+			B.tstride, E->stage1_in.as<int32_t>(), E->st);
+		if (he != hipSuccess) return fail(E, FASIM_E_HIP, "max16 launch failed: %s", hipGetErrorString(he));
+		HIPOK(hipStreamSynchronize(E->st));
+		if (st) st->stage1_word_reruns += (int64_t)sep.size();
+	}
+	rc = upload(E, E->unit_ids, ids.data(), sizeof(int32_t) * nu); if (rc) return rc;
+	L.unit_ids = E->unit_ids.as<int32_t>(); L.nwork = nu; L.qcodes = E->q2.as<uint8_t>(); fill_scores(L.score, false);
+	{ TimedScope ts(E, 0); he = launch_scan(L, E->st); }
+	if (he == hipErrorInvalidValue) return 1;
+	if (he != hipSuccess) return fail(E, FASIM_E_HIP, "scan launch failed: %s", hipGetErrorString(he));
+
+	HIPOK(E->hit_off.ensure(sizeof(int32_t) * nu)); HIPOK(E->hit_cnt.ensure(sizeof(int32_t) * nu));
+	HIPOK(E->thr.ensure(sizeof(int32_t) * nu)); HIPOK(E->hits_total.ensure(64));
+	HIPOK(E->stage1.ensure(sizeof(int32_t) * nu)); HIPOK(E->flags.ensure(sizeof(int32_t) * nu));
+	out.stage1.resize(nu); out.thr.resize(nu); out.hit_off.resize(nu); out.hit_cnt.resize(nu); out.flags.resize(nu);
+	size_t hits_cap = std::max<size_t>(E->hits.cap / 4, (size_t)nu * 128);
+	for (;;) {
+		HIPOK(E->hits.ensure(hits_cap * sizeof(uint32_t)));
+		{ TimedScope ts(E, 4);
+		he = launch_scan_post(E->colmax16.as<uint16_t>(), E->unit_ids.as<int32_t>(), nu, E->unit_len.as<int32_t>(), B.tstride,
+			E->stage1_in.as<int32_t>(), E->hits.as<uint32_t>(), (uint32_t)hits_cap, E->hits_total.as<uint32_t>(),
+			E->hit_off.as<int32_t>(), E->hit_cnt.as<int32_t>(), E->thr.as<int32_t>(), E->stage1.as<int32_t>(), E->flags.as<int32_t>(), E->st); }
+		if (he != hipSuccess) return fail(E, FASIM_E_HIP, "scan_post launch failed: %s", hipGetErrorString(he));
+		uint32_t total = 0;
+		HIPOK(hipMemcpyAsync(&total, E->hits_total.p, sizeof total, hipMemcpyDeviceToHost, E->st));
+		HIPOK(hipStreamSynchronize(E->st));
+		if (total <= hits_cap) { out.hits.resize(total); break; }
+		hits_cap = (size_t)total + 1024;
+	}
+	HIPOK(hipMemcpyAsync(out.hit_off.data(), E->hit_off.p, sizeof(int32_t) * nu, hipMemcpyDeviceToHost, E->st));
+	HIPOK(hipMemcpyAsync(out.hit_cnt.data(), E->hit_cnt.p, sizeof(int32_t) * nu, hipMemcpyDeviceToHost, E->st));
+	HIPOK(hipMemcpyAsync(out.thr.data(), E->thr.p, sizeof(int32_t) * nu, hipMemcpyDeviceToHost, E->st));
+	HIPOK(hipMemcpyAsync(out.stage1.data(), E->stage1.p, sizeof(int32_t) * nu, hipMemcpyDeviceToHost, E->st));
+	HIPOK(hipMemcpyAsync(out.flags.data(), E->flags.p, sizeof(int32_t) * nu, hipMemcpyDeviceToHost, E->st));
+	if (!out.hits.empty()) HIPOK(hipMemcpyAsync(out.hits.data(), E->hits.p, sizeof(uint32_t) * out.hits.size(), hipMemcpyDeviceToHost, E->st));
+	HIPOK(hipStreamSynchronize(E->st));
+
+	// hazard units: the signed lazy-F exit (Q2) may have fired in the reference -> stripe-faithful re-run
+	std::vector<int> hz;
+	for (int u = 0; u < nu; u++) {
+		if (out.flags[u] & 4) return fail(E, FASIM_E_OVERFLOW, "score of unit %d left the 16-bit range", u);
+		if (out.flags[u] & 2) { if (st) st->stage2_overflow_units++; }
+		if (out.flags[u] & 1) hz.push_back(u);
+	}
+	if (!hz.empty()) {
+		if (st) st->hazard_units += (int64_t)hz.size();
+		HIPOK(E->colmax.ensure((size_t)nu * B.tstride));
+		HIPOK(E->max_out.ensure(sizeof(int32_t) * nu));
+		rc = run_striped(E, MODE_PRE, false, whole_unit_probs(B, E->m, &hz), false, E->tcodes.as<uint8_t>(), E->m); if (rc) return rc;
+		std::vector<int32_t> hzids(hz.begin(), hz.end());
+		rc = upload(E, E->unit_ids, hzids.data(), sizeof(int32_t) * hzids.size()); if (rc) return rc;
+		std::vector<int32_t> off2(nu), cnt2(nu);
+		std::vector<uint32_t> hits2;
+		size_t cap2 = std::max<size_t>(E->hits2.cap / 4, hz.size() * 256);
+		for (;;) {
+			HIPOK(E->hits2.ensure(cap2 * sizeof(uint32_t)));
+			{ TimedScope ts(E, 4);
+			he = launch_hits(E->colmax.as<uint8_t>(), E->unit_ids.as<int32_t>(), E->unit_len.as<int32_t>(), E->stage1.as<int32_t>(),
+				(int)hz.size(), B.tstride, E->hits2.as<uint32_t>(), (uint32_t)cap2, E->hits_total.as<uint32_t>(),
+				E->hit_off.as<int32_t>(), E->hit_cnt.as<int32_t>(), E->thr.as<int32_t>(), E->st); }
+			if (he != hipSuccess) return fail(E, FASIM_E_HIP, "hits launch failed: %s", hipGetErrorString(he));
+			uint32_t total = 0;
+			HIPOK(hipMemcpyAsync(&total, E->hits_total.p, sizeof total, hipMemcpyDeviceToHost, E->st));
+			HIPOK(hipStreamSynchronize(E->st));
+			if (total <= cap2) { hits2.resize(total); break; }
+			cap2 = (size_t)total + 1024;
+		}
+		HIPOK(hipMemcpyAsync(off2.data(), E->hit_off.p, sizeof(int32_t) * nu, hipMemcpyDeviceToHost, E->st));
+		HIPOK(hipMemcpyAsync(cnt2.data(), E->hit_cnt.p, sizeof(int32_t) * nu, hipMemcpyDeviceToHost, E->st));
+		if (!hits2.empty()) HIPOK(hipMemcpyAsync(hits2.data(), E->hits2.p, sizeof(uint32_t) * hits2.size(), hipMemcpyDeviceToHost, E->st));
+		HIPOK(hipStreamSynchronize(E->st));
+		// splice: hazard units point into an appended region of the hit array
+		const size_t base = out.hits.size();
+		out.hits.insert(out.hits.end(), hits2.begin(), hits2.end());
+		for (int u : hz) { out.hit_off[u] = (int32_t)(base + off2[u]); out.hit_cnt[u] = cnt2[u]; }
+	}
+	return FASIM_OK;
 }
 
 struct WindowProb { int unit, t0, len; };
@@ -366,6 +482,8 @@ int fasim_engine_create(int device, fasim_engine** out)
 	unsigned hc = std::thread::hardware_concurrency();
 	const char* env = getenv("FASIM_HOST_THREADS");
 	E->host_threads = env ? std::max(1, atoi(env)) : (int)std::min(32u, std::max(1u, hc));
+	const char* v1 = getenv("FASIM_SCAN_V1");
+	E->scan_v1 = v1 && atoi(v1) != 0;
 	*out = E;
 	return FASIM_OK;
 }
@@ -376,7 +494,7 @@ void fasim_engine_destroy(fasim_engine* e)
 	(void)hipSetDevice(e->device);
 	DevBuf* bufs[] = { &e->q1, &e->q2, &e->enc_lut, &e->counter, &e->dna, &e->seg_start, &e->seg_len, &e->enc_ids, &e->tcodes,
 		&e->colmax, &e->probs, &e->max_out, &e->unit_len, &e->stage1, &e->hits, &e->hits_total, &e->hit_off, &e->hit_cnt, &e->thr,
-		&e->ends, &e->bprobs, &e->bout, &e->scratch, &e->dna_res };
+		&e->ends, &e->bprobs, &e->bout, &e->scratch, &e->dna_res, &e->colmax16, &e->unit_ids, &e->flags, &e->stage1_in, &e->hits2 };
 	for (auto& t : e->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
 	for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
 	for (DevBuf* b : bufs) b->release();
@@ -392,7 +510,12 @@ int fasim_set_query(fasim_engine* E, const char* rna, int32_t len)
 	E->rna.assign(rna, rna + len);
 	E->m = len;
 	std::vector<uint8_t> c1(len), c2(len);
-	for (int i = 0; i < len; i++) { c1[i] = code1(rna[i]); c2[i] = code2(rna[i]); }
+	E->query_acgt = true;
+	for (int i = 0; i < len; i++) {
+		c1[i] = code1(rna[i]); c2[i] = code2(rna[i]);
+		const char c = rna[i];
+		if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'a' || c == 'c' || c == 'g' || c == 't')) E->query_acgt = false;
+	}
 	int rc = upload(E, E->q1, c1.data(), len);
 	if (!rc) rc = upload(E, E->q2, c2.data(), len);
 	if (rc) return rc;
@@ -602,8 +725,30 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 				E->enc_ids.as<int32_t>(), nenc, E->enc_lut.as<uint8_t>(), E->tcodes.as<uint8_t>(), tstride, E->st); }
 			if (he != hipSuccess) return fail(E, FASIM_E_HIP, "encode launch failed: %s", hipGetErrorString(he));
 
-			// ---- stage 1
+			// ---- stages 1+2: fused systolic scan (scan.hip); stripe-faithful kernels for hazard units, for
+			//      queries beyond 3072 rows, or when FASIM_SCAN_V1=1
 			double t0 = now_s();
+			std::vector<int32_t> hoff, hcnt, thr;
+			std::vector<uint32_t> hits;
+			bool done_v2 = false;
+			if (!E->scan_v1) {
+				std::vector<char> need1(B.nunit, E->query_acgt ? 0 : 1);
+				if (E->query_acgt) {
+					for (int s = 0; s < nseg; s++) {
+						const char* sg = dna + sidx[s] * step; bool clean = true;
+						for (int i = 0; i < slen[s]; i++) { const char c = sg[i]; if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T')) { clean = false; break; } }
+						if (!clean) for (int k = 0; k < nenc; k++) need1[s * nenc + k] = 1;
+					}
+				}
+				ScanOut so;
+				rc = run_scan_v2(E, B, need1, so, &st);
+				if (rc < 0) return rc;
+				if (rc == 0) { hoff.swap(so.hit_off); hcnt.swap(so.hit_cnt); thr.swap(so.thr); hits.swap(so.hits); done_v2 = true; }
+			}
+			st.t_stage2_s += now_s() - t0;
+			if (!done_v2) {
+			// ---- stage 1
+			t0 = now_s();
 			std::vector<int> s1;
 			rc = run_stage1(E, B, s1, &st.stage1_word_reruns); if (rc) return rc;
 			st.t_stage1_s += now_s() - t0;
@@ -614,13 +759,13 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 			rc = upload(E, E->stage1, s1.data(), sizeof(int32_t) * B.nunit); if (rc) return rc;
 			HIPOK(E->hit_off.ensure(sizeof(int32_t) * B.nunit)); HIPOK(E->hit_cnt.ensure(sizeof(int32_t) * B.nunit));
 			HIPOK(E->thr.ensure(sizeof(int32_t) * B.nunit)); HIPOK(E->hits_total.ensure(64));
-			std::vector<int32_t> hoff(B.nunit), hcnt(B.nunit), thr(B.nunit), pre_max(B.nunit);
-			std::vector<uint32_t> hits;
+			hoff.resize(B.nunit); hcnt.resize(B.nunit); thr.resize(B.nunit);
+			std::vector<int32_t> pre_max(B.nunit);
 			size_t hits_cap = std::max<size_t>(E->hits.cap / 4, (size_t)B.nunit * 128);
 			for (;;) {
 				HIPOK(E->hits.ensure(hits_cap * sizeof(uint32_t)));
 				{ TimedScope ts(E, 4);
-				he = launch_hits(E->colmax.as<uint8_t>(), E->unit_len.as<int32_t>(), E->stage1.as<int32_t>(), B.nunit, tstride,
+				he = launch_hits(E->colmax.as<uint8_t>(), nullptr, E->unit_len.as<int32_t>(), E->stage1.as<int32_t>(), B.nunit, tstride,
 					E->hits.as<uint32_t>(), (uint32_t)hits_cap, E->hits_total.as<uint32_t>(), E->hit_off.as<int32_t>(),
 					E->hit_cnt.as<int32_t>(), E->thr.as<int32_t>(), E->st); }
 				if (he != hipSuccess) return fail(E, FASIM_E_HIP, "hits launch failed: %s", hipGetErrorString(he));
@@ -638,6 +783,7 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 			HIPOK(hipStreamSynchronize(E->st));
 			for (int u = 0; u < B.nunit; u++) if (pre_max[u] == 255) st.stage2_overflow_units++;
 			st.t_stage2_s += now_s() - t0;
+			}
 
 			// ---- candidates (a7) and the window tries (a8) in up to 4 rounds
 			t0 = now_s();
@@ -679,6 +825,8 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 			// ---- host: triplex records per unit (a12-a14), then LongTarget()'s tail filter (a15)
 			t0 = now_s();
 			std::vector<std::vector<HostTriplex>> per_unit(B.nunit);
+			std::vector<char> seg_acgtn(nseg);
+			for (int s = 0; s < nseg; s++) seg_acgtn[s] = only_acgtn(dna + sidx[s] * step, slen[s]) ? 1 : 0;
 			{
 				std::vector<size_t> first(B.nunit + 1, 0);
 				for (const CandState& x : cs) first[x.unit + 1]++;
@@ -693,13 +841,14 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 						const char* seg = dna + sidx[s] * step;
 						const long dna_start = (long)(sidx[s] * step);
 						std::vector<HostTriplex> mine;
+						const bool acgtn = seg_acgtn[s] != 0;
 						for (size_t k = first[u]; k < first[u + 1]; k++) {
 							CandState& x = cs[k];
 							AlignResult al = x.al; int cut = x.cut;
 							if (x.flag == 2) { al = x.best; cut = x.bestcut; }                                  // fastsim.h:238-250
 							if (al.sw_score == 0) continue;                                                    // :253
 							al.ref_begin += x.c.pos - cut + 1; al.ref_end += x.c.pos - cut + 1;                // :254-255
-							convert_triplex(al, E->rna, seg, slen[s], enc, dna_start, p, mine);
+							convert_triplex(al, E->rna, seg, slen[s], enc, dna_start, p, mine, acgtn);
 						}
 						dedup_top(mine, p, per_unit[u]);
 						for (HostTriplex& t : per_unit[u]) { t.seg = (int)sidx[s]; t.enc = enc; }

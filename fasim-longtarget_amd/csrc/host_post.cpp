@@ -148,13 +148,34 @@ static inline float stability(char c1, char c2, int para)
 	return 0;
 }
 
+// letter of the display strand at unit column q (strand==1: complement(seg), reversed for the REV encodings)
+static inline char comp_letter(char c)
+{
+	switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; default: return c; }
+}
+
+bool only_acgtn(const char* seg, int n)
+{
+	for (int i = 0; i < n; i++) { const char c = seg[i]; if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'N')) return false; }
+	return true;
+}
+
 void convert_triplex(const AlignResult& al, const std::string& rna, const char* seg, int n, int enc,
-	long dna_start, const fasim_params& p, std::vector<HostTriplex>& list)
+	long dna_start, const fasim_params& p, std::vector<HostTriplex>& list, bool seg_acgtn)
 {
 	const EncInfo e = enc_info(enc);
 	const char* o = kRuleOut[enc];
+	// complement() drops letters outside ACGTN (rules.h:82-83); only then the display strand has to be
+	// materialised, otherwise its letters are computed on the fly
+	const bool clean = seg_acgtn || e.strand != 1;
 	std::string src;
-	make_src(seg, n, e.strand == 1, e.reversed, src);
+	if (!clean) make_src(seg, n, true, e.reversed, src);
+	auto src_at = [&](int q) -> char {
+		if (!clean) return (q >= 0 && q < (int)src.size()) ? src[q] : '\0';
+		if (q < 0 || q >= n) return '\0';
+		const char c = seg[e.reversed ? n - 1 - q : q];
+		return e.strand == 1 ? comp_letter(c) : c;
+	};
 	// expand the CIGAR from (ref_begin, query_begin): M -> (target, src, rna); I -> ('-','-',rna); D -> (target, src,'-')
 	std::string tgt_al, tts, tfo;
 	int q = al.ref_begin, r = al.query_begin;
@@ -165,7 +186,7 @@ void convert_triplex(const AlignResult& al, const std::string& rna, const char* 
 			else {
 				const char tl = (q >= 0 && q < n) ? map_base(o, seg[e.reversed ? n - 1 - q : q]) : '\0';
 				tgt_al.push_back(tl);
-				tts.push_back(q >= 0 && q < (int)src.size() ? src[q] : '\0');
+				tts.push_back(src_at(q));
 				q++;
 				if (op == 2) tfo.push_back('-'); else tfo.push_back(rna[r++]);
 			}

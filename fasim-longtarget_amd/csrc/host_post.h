@@ -41,7 +41,8 @@ struct HostTriplex {
 
 // convertMyTriplex (fastsim.h:291-414): appends to `list` when nt >= ntMin
 void convert_triplex(const AlignResult& al, const std::string& rna, const char* seg, int n, int enc,
-	long dna_start, const fasim_params& p, std::vector<HostTriplex>& list);
+	long dna_start, const fasim_params& p, std::vector<HostTriplex>& list, bool seg_acgtn);
+bool only_acgtn(const char* seg, int n);
 // tail of fastSIM (fastsim.h:273-288): sort/unique/sort/unique/sort, top 50, identity/stability/nt filter
 void dedup_top(std::vector<HostTriplex>& mine, const fasim_params& p, std::vector<HostTriplex>& out);
 

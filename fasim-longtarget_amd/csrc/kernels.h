@@ -30,11 +30,24 @@ hipError_t launch_encode(const uint8_t* dna_dev, const int32_t* seg_start, const
 	int32_t tstride, hipStream_t st);
 
 // hits above threshold, ordered by column, per unit.  hits[] entries = (pos << 8) | score
-hipError_t launch_hits(const uint8_t* colmax, const int32_t* unit_len, const int32_t* stage1, int32_t nunit,
+// unit_ids == nullptr: units 0..nunit-1 ; otherwise nunit entries of unit_ids are processed
+hipError_t launch_hits(const uint8_t* colmax, const int32_t* unit_ids, const int32_t* unit_len, const int32_t* stage1, int32_t nunit,
 	int32_t tstride, uint32_t* hits, uint32_t hits_cap, uint32_t* hits_total, int32_t* hit_off, int32_t* hit_cnt,
 	int32_t* thr_out, hipStream_t st);
 
 hipError_t launch_banded(const uint8_t* tcodes, const uint8_t* qcodes, const BandProb* probs, int32_t nprob,
 	uint8_t* scratch, BandOut* out, hipStream_t st);
+
+// ---- scan.hip: fused stage-1 + stage-2 systolic kernel ---------------------------------------------
+struct ScanLaunch {
+	const uint8_t* tcodes; const int32_t* unit_ids; const int32_t* unit_len; int32_t nwork; int32_t tstride;
+	uint32_t* counter; const uint8_t* qcodes; int32_t m; int8_t score[25]; uint16_t* colmax16;
+};
+hipError_t launch_scan(const ScanLaunch& L, hipStream_t st);      // hipErrorInvalidValue: query too long for this kernel
+hipError_t launch_scan_post(const uint16_t* colmax16, const int32_t* unit_ids, int32_t nwork, const int32_t* unit_len,
+	int32_t tstride, const int32_t* stage1_in, uint32_t* hits, uint32_t hits_cap, uint32_t* hits_total, int32_t* hit_off,
+	int32_t* hit_cnt, int32_t* thr_out, int32_t* stage1_out, int32_t* flags, hipStream_t st);
+hipError_t launch_max16(const uint16_t* colmax16, const int32_t* unit_ids, int32_t nwork, const int32_t* unit_len,
+	int32_t tstride, int32_t* out, hipStream_t st);
 
 } // namespace fasim

@@ -374,11 +374,11 @@ hipError_t launch_striped(StripedMode mode, bool word, bool quirk, const Striped
 // ------------------------------------------------------------------------------------------------
 // k_hits: one wave per unit
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_hits(const uint8_t* __restrict__ colmax, const int32_t* __restrict__ unit_len,
+__global__ void __launch_bounds__(64) k_hits(const uint8_t* __restrict__ colmax, const int32_t* __restrict__ unit_ids, const int32_t* __restrict__ unit_len,
 	const int32_t* __restrict__ stage1, int32_t tstride, uint32_t* __restrict__ hits, uint32_t hits_cap,
 	uint32_t* __restrict__ hits_total, int32_t* __restrict__ hit_off, int32_t* __restrict__ hit_cnt, int32_t* __restrict__ thr_out)
 {
-	const int unit = blockIdx.x;
+	const int unit = unit_ids ? unit_ids[blockIdx.x] : (int)blockIdx.x;
 	const int lane = threadIdx.x;
 	const int n = unit_len[unit];
 	// minScore = (int)(calc_score_once(...) * 0.8)  -- double multiply, truncation (Fasim-LongTarget.cpp:413)
@@ -408,14 +408,14 @@ __global__ void __launch_bounds__(64) k_hits(const uint8_t* __restrict__ colmax,
 	}
 }
 
-hipError_t launch_hits(const uint8_t* colmax, const int32_t* unit_len, const int32_t* stage1, int32_t nunit,
+hipError_t launch_hits(const uint8_t* colmax, const int32_t* unit_ids, const int32_t* unit_len, const int32_t* stage1, int32_t nunit,
 	int32_t tstride, uint32_t* hits, uint32_t hits_cap, uint32_t* hits_total, int32_t* hit_off, int32_t* hit_cnt,
 	int32_t* thr_out, hipStream_t st)
 {
 	if (nunit <= 0) return hipSuccess;
 	hipError_t err = hipMemsetAsync(hits_total, 0, sizeof(uint32_t), st);
 	if (err != hipSuccess) return err;
-	hipLaunchKernelGGL(k_hits, dim3(nunit), dim3(64), 0, st, colmax, unit_len, stage1, tstride, hits, hits_cap, hits_total,
+	hipLaunchKernelGGL(k_hits, dim3(nunit), dim3(64), 0, st, colmax, unit_ids, unit_len, stage1, tstride, hits, hits_cap, hits_total,
 		hit_off, hit_cnt, thr_out);
 	return hipGetLastError();
 }

@@ -1,0 +1,300 @@
+// fasim-longtarget_amd/csrc/scan.hip -- the fused stage-1 + stage-2 "scan" kernel for gfx950.
+//
+// Textbook Gotoh recurrence over the whole (query x 5 kb segment) matrix of a
+// unit, as a systolic pipeline inside ONE wave64:
+//   * 128 virtual lanes = 64 lanes x 2 packed 16-bit halves; virtual lane v owns RP consecutive query
+//     rows (H and E of those rows live in VGPRs as packed u16 pairs) and processes column (step - v)
+//     at pipeline step `step`, so every dependency (diagonal H, vertical F, running column maximum,
+//     target code) arrives from virtual lane v-1 one step earlier: one DPP wave_shr + v_alignbit each.
+//   * all cell arithmetic is packed 16-bit VALU (v_pk_add_u16 / v_pk_max_i16 / v_pk_sub_u16 clamp):
+//     two DP cells per instruction, ~10 instructions per pair.  No MFMA: this is integer DP.
+//   * the int16 query profile (5 target codes x rows) is staged once per workgroup in LDS, laid out
+//     [code][lane][half][24 rows] with a 112-byte lane stride so the ds_read_b128 fetches (8 rows each)
+//     are bank-conflict free; the two halves of a lane sit on different columns, so each fetches its own
+//     code's rows and a v_perm_b32 merges them.
+//   * the segment's target codes are read 64 columns at a time (one coalesced byte per lane) and fed to
+//     virtual lane 0 with v_readlane; per-column maxima leave virtual lane 127 as one u16 per step.
+//
+// What it replaces: calc_score_once() (stats.h:879-956) and sw_sse2_byte_once() (sswNew.cpp:255-464) for
+// every unit in which the reference's layout-dependent behaviour cannot show: the column maxima are the
+// textbook ones up to the reference's overflow column (Q1, applied in k_scan_post) unless the signed
+// lazy-F exit (Q2, sswNew.cpp:369) can trigger.  Q2 needs an F value >= 132 to cross one of the 15 stripe
+// boundaries k*ceil(m/16) of the reference's striped layout; the kernel raises a per-column hazard bit
+// whenever that is possible (conservatively), and hazard units are re-run by the stripe-faithful kernel
+// (kernels.hip).  Zero-score pad rows (Q3) are part of the profile.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernels.h"
+
+namespace fasim {
+
+typedef short v2s __attribute__((ext_vector_type(2)));
+typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ v2s as_s(v2u x) { return __builtin_bit_cast(v2s, x); }
+__device__ __forceinline__ v2u as_u(v2s x) { return __builtin_bit_cast(v2u, x); }
+__device__ __forceinline__ v2s s_from(int x) { return __builtin_bit_cast(v2s, x); }
+__device__ __forceinline__ int to_int(v2s x) { return __builtin_bit_cast(int, x); }
+__device__ __forceinline__ int to_int(v2u x) { return __builtin_bit_cast(int, x); }
+
+// shift a packed pair down the virtual-lane pipeline: out.lo = x.hi of lane-1 (lane 0: inject), out.hi = x.lo
+__device__ __forceinline__ int vshift(int x, int inject_hi)
+{
+	const int up = __builtin_amdgcn_update_dpp(inject_hi, x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+	return __builtin_amdgcn_alignbit(x, up, 16);
+}
+
+constexpr int SCAN_RS = 24;                 // storage rows per virtual lane in the LDS profile
+constexpr int SCAN_LANE_STRIDE = 112;       // bytes: 2 halves x 24 rows x 2 B + 16 B pad (bank-conflict-free b128)
+constexpr int SCAN_CODE_STRIDE = 64 * SCAN_LANE_STRIDE;   // 7168 B, a multiple of the 256-B bank row
+constexpr int SCAN_DEAD = -16384;           // score of rows beyond the padded query: can never be chosen
+
+struct ScanArgs {
+	const uint8_t* tcodes;       // [unit][tstride]
+	const int32_t* unit_ids;     // work list (indices into tcodes/unit_len), nwork entries
+	const int32_t* unit_len;
+	int32_t nwork;
+	int32_t tstride;
+	uint32_t* counter;
+	const uint8_t* qcodes;       // query codes for this scoring (0..4)
+	int32_t m;                   // query length
+	int32_t m_pad;               // 16 * ceil(m/16): rows [m, m_pad) score 0 (Q3)
+	int32_t seg_len16;           // ceil(m/16): stripe length of the reference's byte kernels
+	int8_t score[25];            // score[t*5+q]
+	uint16_t* colmax16;          // [unit][tstride] : bit 15 = hazard, bits 0..14 = column maximum
+};
+
+template <int RP>
+__global__ void __launch_bounds__(256) k_scan(ScanArgs a)
+{
+	__shared__ __align__(16) uint8_t prof[5 * SCAN_CODE_STRIDE];
+	const int lane = threadIdx.x & 63;
+
+	// ---- stage the int16 profile: prof[t][lane][half][r] -------------------------------------------
+	for (int idx = threadIdx.x; idx < 5 * 128 * SCAN_RS; idx += blockDim.x) {
+		const int r = idx % SCAN_RS;
+		const int v = (idx / SCAN_RS) % 128;
+		const int t = idx / (SCAN_RS * 128);
+		const int row = v * RP + r;
+		int sc = SCAN_DEAD;
+		if (r < RP) {
+			if (row < a.m) sc = a.score[t * 5 + a.qcodes[row]];
+			else if (row < a.m_pad) sc = 0;
+		}
+		*reinterpret_cast<int16_t*>(prof + t * SCAN_CODE_STRIDE + (v >> 1) * SCAN_LANE_STRIDE + (v & 1) * 48 + r * 2) = (int16_t)sc;
+	}
+	__syncthreads();
+
+	// ---- per-lane hazard constants: does a stripe boundary k*seg_len16 (k = 1..15) fall into my rows? --
+	// hb = 0xFFFF in a half that holds a boundary row; fthr = 131 + 4*offset (F_in >= 132 + 4*offset), else 0xFFFF
+	uint32_t hb = 0, fthr = 0xFFFFFFFFu;
+	for (int h = 0; h < 2; h++) {
+		const int v = 2 * lane + h;
+		const int lo = v * RP, hi = lo + RP;      // rows [lo, hi)
+		for (int k = 1; k < 16; k++) {
+			const int b = k * a.seg_len16;
+			if (b >= lo && b < hi && b < a.m_pad) {
+				hb |= 0xFFFFu << (16 * h);
+				const uint32_t cur = (fthr >> (16 * h)) & 0xFFFFu;
+				const uint32_t cand = 131u + 4u * (uint32_t)(b - lo);
+				if (cand < cur) fthr = (fthr & ~(0xFFFFu << (16 * h))) | (cand << (16 * h));
+			}
+		}
+	}
+	const v2u hbmask = __builtin_bit_cast(v2u, hb);
+	const v2u fthr2 = __builtin_bit_cast(v2u, fthr);
+	const uint8_t* pl = prof + lane * SCAN_LANE_STRIDE;
+
+	for (;;) {
+		int w = 0;
+		if (lane == 0) w = (int)atomicAdd(a.counter, 1u);
+		w = __builtin_amdgcn_readfirstlane(w);
+		if (w >= a.nwork) break;
+		const int unit = a.unit_ids[w];
+		const int n = a.unit_len[unit];
+		const uint8_t* tc_unit = a.tcodes + (int64_t)unit * a.tstride;
+		uint16_t* out = a.colmax16 + (int64_t)unit * a.tstride;
+
+		v2s H[RP]; v2u E[RP];
+#pragma unroll
+		for (int r = 0; r < RP; r++) { H[r] = (v2s){ 0, 0 }; E[r] = (v2u){ 0, 0 }; }
+		int tc = 0x00040004;          // target codes of my two halves (N = neutral while the pipeline fills)
+		int hbot = 0, fbot = 0, cm = 0, recv_h_last = 0;
+		int chunk = CODE_N;
+		const int nsteps = n + 127;
+		for (int step = 0; step < nsteps; step++) {
+			if ((step & 63) == 0) {
+				const int c = step + lane;
+				chunk = c < n ? (int)tc_unit[c] : CODE_N;
+			}
+			const int newcode = __builtin_amdgcn_readlane(chunk, step & 63);
+			// hand-over from virtual lane v-1 (computed one step ago)
+			tc = vshift(tc, newcode << 16);
+			const int recv_h = vshift(hbot, 0);
+			const int recv_f = vshift(fbot, 0);
+			const int recv_cm = vshift(cm, 0);
+			const int t_lo = tc & 0xff, t_hi = (tc >> 16) & 0xff;
+			const uint8_t* pa = pl + t_lo * SCAN_CODE_STRIDE;
+			const uint8_t* pb = pl + t_hi * SCAN_CODE_STRIDE + 48;
+			v2s hprev = s_from(recv_h_last);          // H[i0-1][c-1]
+			recv_h_last = recv_h;
+			v2u f = __builtin_bit_cast(v2u, recv_f);
+			v2s lmax = (v2s){ 0, 0 };
+#pragma unroll
+			for (int g = 0; g < (RP + 7) / 8; g++) {
+				const v4i A = *reinterpret_cast<const v4i*>(pa + 16 * g);
+				const v4i B = *reinterpret_cast<const v4i*>(pb + 16 * g);
+#pragma unroll
+				for (int k = 0; k < 8; k++) {
+					const int r = 8 * g + k;
+					if (r < RP) {
+						const int sc = __builtin_amdgcn_perm(B[k >> 1], A[k >> 1], (k & 1) ? 0x07060302 : 0x05040100);
+						const v2s hold = H[r];
+						v2s h = hprev + s_from(sc);
+						h = __builtin_elementwise_max(h, as_s(E[r]));
+						h = __builtin_elementwise_max(h, as_s(f));
+						lmax = __builtin_elementwise_max(lmax, h);
+						H[r] = h;
+						const v2u ho = __builtin_elementwise_sub_sat(as_u(h), (v2u){ GAP_OPEN, GAP_OPEN });
+						E[r] = __builtin_elementwise_max(__builtin_elementwise_sub_sat(E[r], (v2u){ GAP_EXT, GAP_EXT }), ho);
+						f = __builtin_elementwise_max(__builtin_elementwise_sub_sat(f, (v2u){ GAP_EXT, GAP_EXT }), ho);
+						hprev = hold;
+					}
+				}
+			}
+			hbot = to_int(H[RP - 1]);
+			fbot = to_int(f);
+			// running column maximum + hazard bit (bit 15) travelling with the column
+			const v2u hz_a = __builtin_elementwise_sub_sat(as_u(lmax), (v2u){ 147, 147 }) & hbmask;
+			const v2u hz_b = __builtin_elementwise_sub_sat(__builtin_bit_cast(v2u, recv_f), fthr2);
+			const v2u hz = __builtin_elementwise_min(hz_a | hz_b, (v2u){ 1, 1 }) << (v2u){ 15, 15 };
+			const v2u cin = __builtin_bit_cast(v2u, recv_cm);
+			const v2u cval = __builtin_elementwise_max(cin & (v2u){ 0x7fff, 0x7fff }, as_u(lmax));
+			cm = to_int(cval | ((cin | hz) & (v2u){ 0x8000, 0x8000 }));
+			const int cdone = step - 127;
+			if (lane == 63 && cdone >= 0) out[cdone] = (uint16_t)((uint32_t)cm >> 16);
+		}
+	}
+}
+
+template <int RP>
+static hipError_t launch_scan_t(const ScanArgs& a, hipStream_t st)
+{
+	hipError_t err = hipMemsetAsync(a.counter, 0, sizeof(uint32_t), st);
+	if (err != hipSuccess) return err;
+	long waves = a.nwork;
+	long blocks = (waves + 3) / 4;
+	if (blocks > 256 * 4) blocks = 256 * 4;
+	hipLaunchKernelGGL(k_scan<RP>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+	return hipGetLastError();
+}
+
+hipError_t launch_scan(const ScanLaunch& L, hipStream_t st)
+{
+	if (L.nwork <= 0) return hipSuccess;
+	ScanArgs a;
+	a.tcodes = L.tcodes; a.unit_ids = L.unit_ids; a.unit_len = L.unit_len; a.nwork = L.nwork; a.tstride = L.tstride;
+	a.counter = L.counter; a.qcodes = L.qcodes; a.m = L.m; a.m_pad = 16 * ((L.m + 15) / 16); a.seg_len16 = (L.m + 15) / 16;
+	for (int i = 0; i < 25; i++) a.score[i] = L.score[i];
+	a.colmax16 = L.colmax16;
+	const int rp = (a.m_pad + 127) / 128;
+	if (rp <= 8) return launch_scan_t<8>(a, st);
+	if (rp <= 12) return launch_scan_t<12>(a, st);
+	if (rp <= 16) return launch_scan_t<16>(a, st);
+	if (rp <= 20) return launch_scan_t<20>(a, st);
+	if (rp <= 22) return launch_scan_t<22>(a, st);
+	if (rp <= 24) return launch_scan_t<24>(a, st);
+	return hipErrorInvalidValue;         // query longer than 3072 rows: caller uses the striped kernels
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_scan_post: one wave per unit.  Applies the reference's overflow rule (Q1, sswNew.cpp:384-395): the first
+// column whose maximum reaches 251 and everything after it is treated as 0; derives the stage-1 score
+// (own maximum unless a separate stage-1 pass supplied it), the threshold (int)(score*0.8), the hazard
+// flag over columns [0, cut], and the ordered list of columns above the threshold.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_scan_post(const uint16_t* __restrict__ colmax16, const int32_t* __restrict__ unit_ids,
+	const int32_t* __restrict__ unit_len, int32_t tstride, const int32_t* __restrict__ stage1_in, uint32_t* __restrict__ hits,
+	uint32_t hits_cap, uint32_t* __restrict__ hits_total, int32_t* __restrict__ hit_off, int32_t* __restrict__ hit_cnt,
+	int32_t* __restrict__ thr_out, int32_t* __restrict__ stage1_out, int32_t* __restrict__ flags)
+{
+	const int unit = unit_ids[blockIdx.x];
+	const int lane = threadIdx.x;
+	const int n = unit_len[unit];
+	const uint16_t* col = colmax16 + (int64_t)unit * tstride;
+	int mx = 0, cut = n;
+	for (int c0 = 0; c0 < n; c0 += 64) {
+		const int c = c0 + lane;
+		const int v = c < n ? (int)(col[c] & 0x7fff) : 0;
+		mx = max(mx, v);
+		const unsigned long long over = __ballot(v >= 255 - BIAS);
+		if (over && cut == n) cut = c0 + __ffsll((long long)over) - 1;
+	}
+	for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+	int s1 = mx;
+	if (stage1_in && stage1_in[unit] >= 0) s1 = stage1_in[unit];
+	const int thr = (int)((double)s1 * 0.8);          // Fasim-LongTarget.cpp:413
+	int cnt = 0; bool hz = false;
+	for (int c0 = 0; c0 < n; c0 += 64) {
+		const int c = c0 + lane;
+		const int raw = c < n ? (int)col[c] : 0;
+		const int v = raw & 0x7fff;
+		if (c <= cut && (raw & 0x8000)) hz = true;
+		const bool hit = c < cut && v > thr;
+		cnt += __popcll(__ballot(hit));
+	}
+	hz = __ballot(hz) != 0ull;
+	uint32_t off = 0;
+	if (lane == 0) off = atomicAdd(hits_total, (uint32_t)cnt);
+	off = __shfl(off, 0, 64);
+	if (lane == 0) {
+		hit_off[unit] = (int32_t)off; hit_cnt[unit] = cnt; thr_out[unit] = thr; stage1_out[unit] = s1;
+		flags[unit] = (hz ? 1 : 0) | (cut < n ? 2 : 0) | (mx >= 32000 ? 4 : 0);
+	}
+	if ((uint64_t)off + (uint64_t)cnt > hits_cap) return;
+	uint32_t wpos = off;
+	for (int c0 = 0; c0 < n; c0 += 64) {
+		const int c = c0 + lane;
+		const int v = c < n ? (int)(col[c] & 0x7fff) : 0;
+		const bool hit = c < cut && v > thr;
+		const unsigned long long b = __ballot(hit);
+		if (hit) hits[wpos + __popcll(b & ((1ull << lane) - 1ull))] = ((uint32_t)c << 8) | (uint32_t)v;
+		wpos += __popcll(b);
+	}
+}
+
+hipError_t launch_scan_post(const uint16_t* colmax16, const int32_t* unit_ids, int32_t nwork, const int32_t* unit_len,
+	int32_t tstride, const int32_t* stage1_in, uint32_t* hits, uint32_t hits_cap, uint32_t* hits_total, int32_t* hit_off,
+	int32_t* hit_cnt, int32_t* thr_out, int32_t* stage1_out, int32_t* flags, hipStream_t st)
+{
+	if (nwork <= 0) return hipSuccess;
+	hipError_t err = hipMemsetAsync(hits_total, 0, sizeof(uint32_t), st);
+	if (err != hipSuccess) return err;
+	hipLaunchKernelGGL(k_scan_post, dim3((unsigned)nwork), dim3(64), 0, st, colmax16, unit_ids, unit_len, tstride, stage1_in, hits,
+		hits_cap, hits_total, hit_off, hit_cnt, thr_out, stage1_out, flags);
+	return hipGetLastError();
+}
+
+// maximum of the 15-bit values of each listed unit (used for the separate stage-1 pass of units with N)
+__global__ void __launch_bounds__(64) k_max16(const uint16_t* __restrict__ colmax16, const int32_t* __restrict__ unit_ids,
+	const int32_t* __restrict__ unit_len, int32_t tstride, int32_t* __restrict__ out)
+{
+	const int unit = unit_ids[blockIdx.x];
+	const int n = unit_len[unit];
+	const uint16_t* col = colmax16 + (int64_t)unit * tstride;
+	int mx = 0;
+	for (int c = threadIdx.x; c < n; c += 64) mx = max(mx, (int)(col[c] & 0x7fff));
+	for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+	if (threadIdx.x == 0) out[unit] = mx;
+}
+
+hipError_t launch_max16(const uint16_t* colmax16, const int32_t* unit_ids, int32_t nwork, const int32_t* unit_len,
+	int32_t tstride, int32_t* out, hipStream_t st)
+{
+	if (nwork <= 0) return hipSuccess;
+	hipLaunchKernelGGL(k_max16, dim3((unsigned)nwork), dim3(64), 0, st, colmax16, unit_ids, unit_len, tstride, out);
+	return hipGetLastError();
+}
+
+} // namespace fasim

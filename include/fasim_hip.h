@@ -96,11 +96,13 @@ typedef struct fasim_scan_stats {
 	int64_t candidates, align_calls, align_word_reruns, stage2_overflow_units, stage1_word_reruns;
 	int64_t logical_cells;              /* m * sum(len(segment)) * n_enc                  */
 	double  t_total_s, t_stage1_s, t_stage2_s, t_stage3_s, t_host_s;   /* host wall clock per phase       */
-	/* HIP-event time of the kernels, summed over launches on the engine's stream (index: 0 stage-1 striped,
-	 * 1 stage-2 striped, 2 stage-3 striped fwd+rev, 3 banded traceback, 4 encode+hits)                 */
+	/* HIP-event time of the kernels, summed over launches on the engine's stream.  index: 0 k_scan (fused
+	 * stage 1+2), 1 k_striped stage-1/2 (hazard re-runs, long queries), 2 stage-3 alignment kernels,
+	 * 3 traceback kernels, 4 encode + hit extraction                                                     */
 	double  kernel_ms[5];
 	int64_t kernel_launches[5];
 	int64_t cells_stage1, cells_stage2, cells_stage3;   /* DP cells actually executed (stage 3: fwd + rev)   */
+	int64_t hazard_units;               /* units re-run by the stripe-faithful kernel (possible Q2)  */
 } fasim_scan_stats;
 
 typedef struct fasim_result {
