@@ -1,0 +1,444 @@
+// fasim-longtarget_amd/csrc/align.hip -- stage 3 (window alignments) for gfx950.
+//
+//   k_build_stream  concatenates the target codes of all windows of a round into one column stream
+//                   [void, void, c0 .. cL-1(last)] per window
+//   k_align_fwd     forward pass of ssw_align (sswNew.cpp:1470-1495) as the same systolic wave pipeline as
+//                   scan.hip, fed by the window stream WITHOUT draining between windows: two "void" columns
+//                   (score -inf, gap registers = 0xFFFF so that the saturating subtractions clear E and F)
+//                   reset the DP state in flight.  DP values are kept scaled by 32 so that the low 5 bits of
+//                   every H can carry (31 - row-in-lane): one v_pk_max then yields, per column, the maximum
+//                   AND the smallest row that holds it (read_end, sswNew.cpp:621-629).
+//   k_finish        per alignment (one thread): the reverse pass (sswNew.cpp:1508-1520) and banded_sw
+//                   (sswNew.cpp:1071-1259).  Every alignment of the winning score inside the reverse
+//                   rectangle ends in its corner (ref_end is the FIRST column reaching the score, read_end
+//                   the SMALLEST such row), so the reverse pass only has to follow paths that start in that
+//                   corner: a pruned origin-anchored DP over a few hundred cells instead of (read_end+1) x
+//                   (ref_end+1).  See DESIGN.md "reverse pass" for the argument.
+//
+// Windows in which the reference's signed lazy-F exit (Q2) could fire are flagged and re-run by the
+// stripe-faithful kernel (kernels.hip).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernels.h"
+
+namespace fasim {
+
+typedef short v2s __attribute__((ext_vector_type(2)));
+typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ v2s a_s(v2u x) { return __builtin_bit_cast(v2s, x); }
+__device__ __forceinline__ v2u a_u(v2s x) { return __builtin_bit_cast(v2u, x); }
+__device__ __forceinline__ int a_i(v2s x) { return __builtin_bit_cast(int, x); }
+__device__ __forceinline__ int a_i(v2u x) { return __builtin_bit_cast(int, x); }
+__device__ __forceinline__ v2u u_from(int x) { return __builtin_bit_cast(v2u, x); }
+__device__ __forceinline__ v2s s_fromi(int x) { return __builtin_bit_cast(v2s, x); }
+
+__device__ __forceinline__ int vshift2(int x, int inject_hi)
+{
+	const int up = __builtin_amdgcn_update_dpp(inject_hi, x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+	return __builtin_amdgcn_alignbit(x, up, 16);
+}
+
+constexpr int AL_RS = 24;
+constexpr int AL_LANE_STRIDE = 112;
+constexpr int AL_CODE_STRIDE = 64 * AL_LANE_STRIDE;
+constexpr int AL_SCALE = 32;                 // DP values are multiples of 32
+constexpr int AL_NEG = -32768;               // void / dead score: H <= 31360 so H + AL_NEG < 0 always
+constexpr int CODE_VOID = 5;
+constexpr int TAG_LAST = 8;                  // bit 3 of a stream byte: last column of a window
+constexpr int TAG_HZ = 16;                   // bit 4 (in flight only): hazard seen in this column
+
+// ------------------------------------------------------------------------------------------------
+__global__ void k_build_stream(const uint8_t* __restrict__ tcodes, const FwdProb* __restrict__ probs, int32_t nprob,
+	uint8_t* __restrict__ stream)
+{
+	const int p = blockIdx.x;
+	if (p >= nprob) return;
+	const FwdProb pb = probs[p];
+	uint8_t* s = stream + pb.stream_off;
+	for (int c = threadIdx.x; c < pb.len + 2; c += blockDim.x) {
+		uint8_t v;
+		if (c < 2) v = CODE_VOID;
+		else { v = tcodes[pb.tbase + (c - 2)]; if (c - 2 == pb.len - 1) v |= TAG_LAST; }
+		s[c] = v;
+	}
+}
+
+hipError_t launch_build_stream(const uint8_t* tcodes, const FwdProb* probs, int32_t nprob, uint8_t* stream, hipStream_t st)
+{
+	if (nprob <= 0) return hipSuccess;
+	hipLaunchKernelGGL(k_build_stream, dim3((unsigned)nprob), dim3(64), 0, st, tcodes, probs, nprob, stream);
+	return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+struct FwdArgs {
+	const uint8_t* stream;
+	const FwdProb* probs;
+	const int32_t* task_first;     // ntask + 1 problem indices
+	int32_t ntask;
+	uint32_t* counter;
+	const uint8_t* qcodes;
+	int32_t m, m_pad, seg_len16;
+	FwdOut* out;
+};
+
+template <int RP>
+__global__ void __launch_bounds__(256) k_align_fwd(FwdArgs a)
+{
+	__shared__ __align__(16) uint8_t prof[6 * AL_CODE_STRIDE];
+	const int lane = threadIdx.x & 63;
+
+	for (int idx = threadIdx.x; idx < 6 * 128 * AL_RS; idx += blockDim.x) {
+		const int r = idx % AL_RS;
+		const int v = (idx / AL_RS) % 128;
+		const int t = idx / (AL_RS * 128);
+		const int vq = a.seg_len16 / 8, vrem = a.seg_len16 % 8, vj = v & 7;
+		const int rows_v = vq + (vj < vrem ? 1 : 0);
+		const int row = (v >> 3) * a.seg_len16 + vj * vq + (vj < vrem ? vj : vrem) + r;
+		int sc = AL_NEG;
+		if (t < 5 && r < rows_v) {
+			if (row < a.m) { const int q = a.qcodes[row]; sc = ((q == t && t < 4) ? 5 : -4) * AL_SCALE; }
+			else sc = 0;
+		}
+		*reinterpret_cast<int16_t*>(prof + t * AL_CODE_STRIDE + (v >> 1) * AL_LANE_STRIDE + (v & 1) * 48 + r * 2) = (int16_t)sc;
+	}
+	__syncthreads();
+
+	// stripe-aligned layout (see scan.hip): virtual lane 8k starts the reference's stripe k
+	uint32_t fthr = 0xFFFFFFFFu, act = 0;
+	int row0[2];
+	for (int h = 0; h < 2; h++) {
+		const int v = 2 * lane + h;
+		const int vq = a.seg_len16 / 8, vrem = a.seg_len16 % 8, vj = v & 7;
+		row0[h] = (v >> 3) * a.seg_len16 + vj * vq + (vj < vrem ? vj : vrem);
+		if (vj == 0 && v > 0) fthr = (fthr & ~(0xFFFFu << (16 * h))) | ((131u * AL_SCALE + (AL_SCALE - 1)) << (16 * h));
+		if (vrem == 0 || vj < vrem) act |= 0xFFFFu << (16 * h);
+	}
+	const v2u fthr2 = u_from((int)fthr);
+	const v2u actm = u_from((int)act);
+	const uint8_t* pl = prof + lane * AL_LANE_STRIDE;
+	// (31 - r) tags for the row keys, and the base of the global-row key of my two virtual lanes
+	const int kbase_lo = 0xFFFF - row0[0] - 31, kbase_hi = 0xFFFF - row0[1] - 31;
+
+	for (;;) {
+		int w = 0;
+		if (lane == 0) w = (int)atomicAdd(a.counter, 1u);
+		w = __builtin_amdgcn_readfirstlane(w);
+		if (w >= a.ntask) break;
+		const int p0 = a.task_first[w], p1 = a.task_first[w + 1];
+		if (p1 <= p0) continue;
+		const int s0 = a.probs[p0].stream_off;
+		const FwdProb lastp = a.probs[p1 - 1];
+		const int slen = lastp.stream_off + lastp.len + 2 - s0;
+		const uint8_t* str = a.stream + s0;
+
+		v2s H[RP]; v2u E[RP];
+#pragma unroll
+		for (int r = 0; r < RP; r++) { H[r] = (v2s){ 0, 0 }; E[r] = (v2u){ 0, 0 }; }
+		int tc = (CODE_VOID << 16) | CODE_VOID;
+		int hbot = 0, fbot = 0, recv_h_last = 0;
+		uint32_t klo = 0, khi = 0;           // (colmax << 16) | (0xFFFF - row) of my two virtual lanes' columns
+		int chunk = CODE_VOID;
+		// pipe-end state (meaningful in lane 63)
+		int pidx = p0, cidx = 0, runmax = 0, end_ref = -1, end_read = 0, hzflag = 0, over = 0;
+		const int nsteps = slen + 127;
+		for (int step = 0; step < nsteps; step++) {
+			if ((step & 63) == 0) {
+				const int c = step + lane;
+				chunk = c < slen ? (int)str[c] : CODE_VOID;
+			}
+			const int newcode = __builtin_amdgcn_readlane(chunk, step & 63);
+			tc = vshift2(tc, newcode << 16);
+			const int recv_h = vshift2(hbot, 0);
+			const int recv_f = vshift2(fbot, 0);
+			const uint32_t kup = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)khi, 0x138, 0xf, 0xf, false);
+			const uint32_t kin_lo = kup, kin_hi = klo;       // from virtual lane v-1 (same column, one step ago)
+			const int t_lo = tc & 7, t_hi = (tc >> 16) & 7;
+			const uint8_t* pa = pl + t_lo * AL_CODE_STRIDE;
+			const uint8_t* pb = pl + t_hi * AL_CODE_STRIDE + 48;
+			// void columns clear E and F: the saturating subtractions use 0xFFFF instead of 4*32 / 16*32
+			const v2u isvoid = (v2u){ (unsigned short)(t_lo == CODE_VOID ? 0xFFFF : 0), (unsigned short)(t_hi == CODE_VOID ? 0xFFFF : 0) };
+			const v2u dec = isvoid | (v2u){ GAP_EXT * AL_SCALE, GAP_EXT * AL_SCALE };
+			const v2u gapo = isvoid | (v2u){ GAP_OPEN * AL_SCALE, GAP_OPEN * AL_SCALE };
+			v2s hprev = s_fromi(recv_h_last);
+			recv_h_last = recv_h;
+			v2u f = u_from(recv_f);
+			v2s lkey = (v2s){ 0, 0 };
+#pragma unroll
+			for (int g = 0; g < (RP + 7) / 8; g++) {
+				const v4i A = *reinterpret_cast<const v4i*>(pa + 16 * g);
+				const v4i B = *reinterpret_cast<const v4i*>(pb + 16 * g);
+#pragma unroll
+				for (int k = 0; k < 8; k++) {
+					const int r = 8 * g + k;
+					if (r < RP) {
+						const int sc = __builtin_amdgcn_perm(B[k >> 1], A[k >> 1], (k & 1) ? 0x07060302 : 0x05040100);
+						const v2s hold = H[r];
+						v2s h = hprev + s_fromi(sc);
+						h = __builtin_elementwise_max(h, a_s(E[r]));
+						h = __builtin_elementwise_max(h, a_s(f));
+						H[r] = h;
+						const v2u ho = __builtin_elementwise_sub_sat(a_u(h), gapo);
+						E[r] = __builtin_elementwise_max(__builtin_elementwise_sub_sat(E[r], dec), ho);
+						const v2u fnew = __builtin_elementwise_max(__builtin_elementwise_sub_sat(f, dec), ho);
+						const v2s key = h | (v2s){ (short)(31 - r), (short)(31 - r) };
+						if (r == RP - 1) {
+							f = (fnew & actm) | (f & ~actm);
+							lkey = __builtin_elementwise_max(lkey, a_s(a_u(key) & actm));
+							if (RP > 1) hbot = a_i((a_u(h) & actm) | (a_u(H[RP > 1 ? RP - 2 : 0]) & ~actm));
+							else hbot = a_i(h);
+						} else {
+							f = fnew;
+							lkey = __builtin_elementwise_max(lkey, key);
+						}
+						hprev = hold;
+					}
+				}
+			}
+			fbot = a_i(f);
+			// hazard (possible Q2): the F entering a stripe-starting virtual lane is >= 132
+			const v2u hz_b = __builtin_elementwise_sub_sat(u_from(recv_f), fthr2);
+			const v2u hzb = __builtin_elementwise_min(hz_b, (v2u){ 1, 1 }) << (v2u){ 4, 4 };
+			tc |= a_i(hzb);
+			// per-column (max, smallest row) keys
+			const uint32_t lk = (uint32_t)a_i(lkey);
+			const uint32_t loc_lo = (((lk & 0xFFFFu) >> 5) << 16) | (uint32_t)(kbase_lo + (int)(lk & 31u));
+			const uint32_t loc_hi = ((lk >> 21) << 16) | (uint32_t)(kbase_hi + (int)((lk >> 16) & 31u));
+			klo = kin_lo > loc_lo ? kin_lo : loc_lo;
+			khi = kin_hi > loc_hi ? kin_hi : loc_hi;
+
+			// ---- pipe end: virtual lane 127 has just finished one column of the stream ---------------------
+			if (lane == 63) {
+				const int tag = (tc >> 16) & 0xff;
+				if ((tag & 7) != CODE_VOID) {
+					const int colmax = (int)(khi >> 16);
+					if (!over && (tag & TAG_HZ)) hzflag = 1;
+					if (colmax > runmax) { runmax = colmax; end_ref = cidx; end_read = 0xFFFF - (int)(khi & 0xFFFFu); }
+					if (runmax >= 255 - BIAS) over = 1;
+					cidx++;
+					if (tag & TAG_LAST) {
+						FwdOut o;
+						o.score = runmax; o.ref_end = end_ref; o.read_end = end_read < a.m - 1 ? end_read : a.m - 1;
+						o.flags = hzflag;
+						a.out[pidx] = o;
+						pidx++; cidx = 0; runmax = 0; end_ref = -1; end_read = 0; hzflag = 0; over = 0;
+					}
+				}
+			}
+		}
+	}
+}
+
+template <int RP>
+static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st)
+{
+	hipError_t err = hipMemsetAsync(a.counter, 0, sizeof(uint32_t), st);
+	if (err != hipSuccess) return err;
+	long blocks = ((long)a.ntask + 3) / 4;
+	if (blocks > 256 * 3) blocks = 256 * 3;
+	hipLaunchKernelGGL(k_align_fwd<RP>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+	return hipGetLastError();
+}
+
+hipError_t launch_align_fwd(const FwdLaunch& L, hipStream_t st)
+{
+	if (L.ntask <= 0) return hipSuccess;
+	FwdArgs a;
+	a.stream = L.stream; a.probs = L.probs; a.task_first = L.task_first; a.ntask = L.ntask; a.counter = L.counter;
+	a.qcodes = L.qcodes; a.m = L.m; a.m_pad = 16 * ((L.m + 15) / 16); a.seg_len16 = (L.m + 15) / 16; a.out = L.out;
+	if (a.seg_len16 < 8) return hipErrorInvalidValue;
+	switch ((a.seg_len16 + 7) / 8) {
+#define FASIM_FWD_CASE(N) case N: return launch_fwd_t<N>(a, st);
+	FASIM_FWD_CASE(1) FASIM_FWD_CASE(2) FASIM_FWD_CASE(3) FASIM_FWD_CASE(4) FASIM_FWD_CASE(5) FASIM_FWD_CASE(6)
+	FASIM_FWD_CASE(7) FASIM_FWD_CASE(8) FASIM_FWD_CASE(9) FASIM_FWD_CASE(10) FASIM_FWD_CASE(11) FASIM_FWD_CASE(12)
+	FASIM_FWD_CASE(13) FASIM_FWD_CASE(14) FASIM_FWD_CASE(15) FASIM_FWD_CASE(16) FASIM_FWD_CASE(17) FASIM_FWD_CASE(18)
+	FASIM_FWD_CASE(19) FASIM_FWD_CASE(20) FASIM_FWD_CASE(21) FASIM_FWD_CASE(22) FASIM_FWD_CASE(23) FASIM_FWD_CASE(24)
+#undef FASIM_FWD_CASE
+	default: break;
+	}
+	return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_finish
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int swsc(int a, int b) { return (a == b && a < 4) ? 5 : -4; }
+__device__ __forceinline__ uint32_t cig(int len, int op) { return ((uint32_t)len << 4) | (uint32_t)op; }
+
+constexpr int G_ROWS = 640;          // rows the origin-anchored reverse DP may touch
+constexpr int G_NEG = -1000000;
+
+// Reverse pass.  Returns 0 and sets (*ref_begin, *read_begin), or 1 when it cannot decide (caller re-runs the
+// window on the stripe-faithful kernel).
+__device__ int reverse_pass(const uint8_t* __restrict__ tw /* window codes */, const uint8_t* __restrict__ q, int S, int ref_end,
+	int read_end, int32_t* Gp, int32_t* Ep, int* ref_begin, int* read_begin)
+{
+	const int R = read_end + 1, C = ref_end + 1;
+	// column 0
+	const int g0 = swsc(q[read_end], tw[ref_end]);
+	if (g0 <= 0) return 1;
+	if (g0 == S) { *ref_begin = ref_end; *read_begin = read_end; return 0; }
+	int lo = 0, hi = 0;
+	Gp[0] = g0; Ep[0] = G_NEG;
+	for (int i = 1; i < R && i < G_ROWS; i++) {
+		const int g = g0 - GAP_OPEN - GAP_EXT * (i - 1);
+		const int rest = min(R - 1 - i, C - 1);
+		if (g <= 0 || g + 5 * rest < S) break;
+		Gp[i] = g; Ep[i] = G_NEG; hi = i;
+	}
+	for (int j = 1; j < C; j++) {
+		const int tcode = tw[ref_end - j];
+		int F = G_NEG;
+		int diag = G_NEG;                // old G[i-1]
+		int nlo = -1, nhi = -1;
+		const int colrest = C - 1 - j;
+		for (int i = lo; i < R; i++) {
+			if (i >= G_ROWS) return 1;
+			const bool in = (i <= hi);
+			const int gp = in ? Gp[i] : G_NEG;
+			const int ep = in ? Ep[i] : G_NEG;
+			int e = max(ep - GAP_EXT, gp - GAP_OPEN);
+			int g = diag > G_NEG / 2 ? diag + swsc(q[read_end - i], tcode) : G_NEG;
+			g = max(g, max(e, F));
+			const int rest = min(R - 1 - i, colrest);
+			if (g <= 0 || g + 5 * rest < S) g = G_NEG;
+			if (e <= 0 || e + 5 * rest < S) e = G_NEG;
+			if (g == S) { *ref_begin = ref_end - j; *read_begin = read_end - i; return 0; }
+			diag = gp;
+			Gp[i] = g; Ep[i] = e;
+			if (g > G_NEG / 2 || e > G_NEG / 2) { if (nlo < 0) nlo = i; nhi = i; }
+			F = max(F - GAP_EXT, g - GAP_OPEN);
+			if (F <= 0) F = G_NEG;
+			if (i > hi && F <= G_NEG / 2 && diag <= G_NEG / 2) break;   // nothing can reach the rows below
+		}
+		if (nlo < 0) return 1;           // no path left: cannot happen for a consistent forward result
+		lo = nlo; hi = nhi;
+	}
+	return 1;                            // score never reached inside the rectangle: let the exact kernel decide
+}
+
+__global__ void __launch_bounds__(64) k_finish(const uint8_t* __restrict__ tcodes, const uint8_t* __restrict__ qcodes,
+	const FwdProb* __restrict__ probs, const FwdOut* __restrict__ fwd, int32_t nprob, uint8_t* __restrict__ scratch,
+	int32_t scratch_cap, AlignOutDev* __restrict__ out)
+{
+	const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+	if (pi >= nprob) return;
+	const FwdProb pb = probs[pi];
+	const FwdOut fo = fwd[pi];
+	AlignOutDev* o = out + pi;
+	o->sw_score = 0; o->ref_begin = 0; o->ref_end = fo.ref_end; o->query_begin = 0; o->query_end = fo.read_end; o->cigar_len = 0;
+	if (fo.flags != 0) { o->status = 10; return; }                 // possible Q2: stripe-faithful re-run
+	if (fo.score <= 0 || fo.ref_end < 0) { o->status = 0; return; }   // nothing aligned
+	uint8_t* my = scratch + (int64_t)pi * scratch_cap;
+	const uint8_t* tw = tcodes + pb.tbase;
+	int ref_begin = 0, read_begin = 0;
+	{
+		int32_t* Gp = reinterpret_cast<int32_t*>(my);
+		int32_t* Ep = Gp + G_ROWS;
+		if (reverse_pass(tw, qcodes, fo.score, fo.ref_end, fo.read_end, Gp, Ep, &ref_begin, &read_begin)) { o->status = 11; return; }
+	}
+	o->ref_begin = ref_begin; o->query_begin = read_begin;
+	// ---- banded_sw (sswNew.cpp:1071-1259)
+	const uint8_t* ref = tw + ref_begin;
+	const uint8_t* read = qcodes + read_begin;
+	const int refLen = fo.ref_end - ref_begin + 1, readLen = fo.read_end - read_begin + 1, score = fo.score;
+	int wmax = scratch_cap / 64;
+	if (wmax > 4099) wmax = 4099;
+	if (wmax < 8) wmax = 8;
+	int32_t* h_b = reinterpret_cast<int32_t*>(my);
+	int32_t* e_b = h_b + wmax;
+	int32_t* h_c = e_b + wmax;
+	int8_t* direction = reinterpret_cast<int8_t*>(h_c + wmax);
+	const long dir_cap = (long)scratch_cap - (long)3 * wmax * 4;
+	int band = (refLen > readLen ? refLen - readLen : readLen - refLen) + 1;
+	int maxv = 0, width = 0, width_d = 0;
+	do {
+		width = band * 2 + 3; width_d = band * 2 + 1;
+		if (width + 1 > wmax || (long)width_d * readLen * 3 + 3 > dir_cap) { o->status = 2; return; }
+		for (int j = 1; j < width - 1; j++) h_b[j] = 0;
+		for (int i = 0; i < readLen; i++) {
+			int beg = 0, end = refLen - 1, u = 0;
+			if (i - band > beg) beg = i - band;
+			if (i + band < end) end = i + band;
+			const int edge = end + 1 < width - 1 ? end + 1 : width - 1;
+			int f = 0;
+			h_b[0] = 0; e_b[0] = 0; h_b[edge] = 0; e_b[edge] = 0; h_c[0] = 0;
+			int8_t* line = direction + (long)width_d * i * 3;
+			const int x = i - band > 0 ? i - band : 0;
+			const int xp = i - 1 - band > 0 ? i - 1 - band : 0;
+			const int rd = read[i];
+			for (int j = beg; j <= end; j++) {
+				u = j - x + 1;
+				const int e = j - xp + 1, b = j - x, d = j - xp;
+				int8_t* cell = line + (j - x) * 3;
+				int t1 = i == 0 ? -GAP_OPEN : h_b[e] - GAP_OPEN;
+				int t2 = i == 0 ? -GAP_EXT : e_b[e] - GAP_EXT;
+				const int ev = t1 > t2 ? t1 : t2;
+				e_b[u] = ev;
+				const int8_t de = t1 > t2 ? 3 : 2;
+				cell[0] = de;
+				t1 = h_c[b] - GAP_OPEN;
+				t2 = f - GAP_EXT;
+				f = t1 > t2 ? t1 : t2;
+				const int8_t df = t1 > t2 ? 5 : 4;
+				cell[1] = df;
+				const int e1 = ev > 0 ? ev : 0;
+				const int f1 = f > 0 ? f : 0;
+				t1 = e1 > f1 ? e1 : f1;
+				t2 = h_b[d] + swsc(ref[j], rd);
+				const int hv = t1 > t2 ? t1 : t2;
+				h_c[u] = hv;
+				if (hv > maxv) maxv = hv;
+				cell[2] = (t1 <= t2) ? (int8_t)1 : (e1 > f1 ? de : df);
+			}
+			for (int j = 1; j <= u; j++) h_b[j] = h_c[j];
+		}
+		band *= 2;
+		if (maxv < score && band > 4 * (refLen + readLen) + 16) { o->status = 3; return; }
+	} while (maxv < score);
+	band /= 2;
+	uint32_t rc[ALIGN_MAX_CIGAR];
+	int l = 0;
+	int i = readLen - 1, j = refLen - 1, e = 0, state = 2, op = 0, prev_op = 0, status = 0;
+	while (i > 0) {
+		const int x = i - band > 0 ? i - band : 0;
+		int beg = 0, end = refLen - 1;
+		if (i - band > beg) beg = i - band;
+		if (i + band < end) end = i + band;
+		if (j < beg || j > end) { status = 3; break; }
+		const int8_t dv = direction[(long)width_d * i * 3 + (j - x) * 3 + state];
+		if (dv == 1) { --i; --j; state = 2; op = 0; }
+		else if (dv == 2) { --i; state = 0; op = 1; }
+		else if (dv == 3) { --i; state = 2; op = 1; }
+		else if (dv == 4) { --j; state = 1; op = 2; }
+		else if (dv == 5) { --j; state = 2; op = 2; }
+		else { status = 1; break; }
+		if (op == prev_op) ++e;
+		else {
+			if (l >= ALIGN_MAX_CIGAR) { status = 4; break; }
+			rc[l++] = cig(e, prev_op);
+			prev_op = op; e = 1;
+		}
+	}
+	if (status == 0) {
+		if (op == 0) { if (l >= ALIGN_MAX_CIGAR) status = 4; else rc[l++] = cig(e + 1, 0); }
+		else { if (l + 2 > ALIGN_MAX_CIGAR) status = 4; else { rc[l++] = cig(e, op); rc[l++] = cig(1, 0); } }
+	}
+	o->status = status;
+	if (status != 0) return;
+	o->sw_score = score;
+	o->cigar_len = l;
+	for (int k = 0; k < l; k++) o->cigar[k] = rc[l - 1 - k];
+}
+
+hipError_t launch_finish(const uint8_t* tcodes, const uint8_t* qcodes, const FwdProb* probs, const FwdOut* fwd, int32_t nprob,
+	uint8_t* scratch, int32_t scratch_cap, AlignOutDev* out, hipStream_t st)
+{
+	if (nprob <= 0) return hipSuccess;
+	hipLaunchKernelGGL(k_finish, dim3((nprob + 63) / 64), dim3(64), 0, st, tcodes, qcodes, probs, fwd, nprob, scratch, scratch_cap, out);
+	return hipGetLastError();
+}
+
+} // namespace fasim

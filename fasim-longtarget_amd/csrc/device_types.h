@@ -50,6 +50,23 @@ struct BandOut {
 
 constexpr int MAX_CIGAR_DEV = 62;
 
+// ---- stage 3 v2 (align.hip) ------------------------------------------------------------------------
+struct FwdProb {
+	int64_t tbase;        // target-code offset of the window's first column
+	int32_t len;          // window length L
+	int32_t stream_off;   // offset of the window's first (void) byte in the column stream
+};
+struct FwdOut { int32_t score, ref_end, read_end, flags; };   // flags != 0: possible Q2 -> stripe-faithful re-run
+constexpr int ALIGN_MAX_CIGAR = 48;
+struct AlignOutDev {
+	int32_t sw_score, ref_begin, ref_end, query_begin, query_end;
+	int32_t status;       // 0 ok; 1 traceback error (reference returns NULL); 3 undefined behaviour in the reference;
+	                      // 2/4/10/11: re-run on the stripe-faithful path (scratch, cigar length, hazard, reverse pass undecided)
+	int32_t cigar_len;
+	uint32_t cigar[ALIGN_MAX_CIGAR];
+	int32_t pad;
+};
+
 // packed 4-bit score table: entry q (0..5) of row t = score(t,q)+BIAS
 struct ScoreLut { uint32_t row[5]; };
 

@@ -57,7 +57,9 @@ struct fasim_engine {
 	int m = 0;
 	ScoreLut lut1, lut2;
 	DevBuf q1, q2, enc_lut, counter, dna, seg_start, seg_len, enc_ids, tcodes, colmax, probs, max_out, unit_len,
-		stage1, hits, hits_total, hit_off, hit_cnt, thr, ends, bprobs, bout, scratch, colmax16, unit_ids, flags, stage1_in, hits2;
+		stage1, hits, hits_total, hit_off, hit_cnt, thr, ends, bprobs, bout, scratch, colmax16, unit_ids, flags, stage1_in, hits2,
+		fprobs, ftasks, fstream, fout, aout;
+	bool align_v1 = false;        // FASIM_ALIGN_V1=1: force the stripe-faithful kernels for stage 3
 	bool query_acgt = true;       // query holds only A,C,G,T: stage-1 and stage-2 scoring coincide on N-free segments
 	bool scan_v1 = false;         // FASIM_SCAN_V1=1: force the stripe-faithful kernels for stages 1 and 2
 	int host_threads = 1;
@@ -426,6 +428,72 @@ int run_align(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>
 	return FASIM_OK;
 }
 
+// a9-a11 through the systolic forward kernel + per-alignment finish kernel (align.hip); windows that may hit
+// the reference's layout-dependent behaviour are re-run by run_align() above.
+int run_align_v2(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, std::vector<AlignResult>& out,
+	fasim_scan_stats* stats)
+{
+	const int n = (int)W.size();
+	if (!n) { out.clear(); return FASIM_OK; }
+	const int seg16 = (E->m + 15) / 16;
+	bool fits = !E->align_v1 && seg16 >= 8 && seg16 <= 192;      // 128 virtual lanes x up to 24 rows
+	if (fits) for (int k = 0; k < n; k++) if (W[k].len > 200 || W[k].len <= 0) { fits = false; break; }
+	if (!fits) return run_align(E, B, W, out, stats);
+	out.assign(n, AlignResult());
+	std::vector<FwdProb> probs(n);
+	int64_t off = 0;
+	for (int k = 0; k < n; k++) {
+		probs[k].tbase = (int64_t)W[k].unit * B.tstride + W[k].t0; probs[k].len = W[k].len; probs[k].stream_off = (int32_t)off;
+		off += W[k].len + 2;
+	}
+	if (off > 0x7fff0000ll) return fail(E, FASIM_E_UNSUPPORTED, "window stream of one round exceeds 2 GiB; lower FASIM_SEG_BATCH");
+	int per_task = std::max(8, std::min(64, n / 3072));
+	std::vector<int32_t> tasks;
+	for (int k = 0; k < n; k += per_task) tasks.push_back(k);
+	tasks.push_back(n);
+	const int ntask = (int)tasks.size() - 1;
+	const int scratch_cap = 8192;
+	int rc = upload(E, E->fprobs, probs.data(), sizeof(FwdProb) * n); if (rc) return rc;
+	rc = upload(E, E->ftasks, tasks.data(), sizeof(int32_t) * tasks.size()); if (rc) return rc;
+	HIPOK(E->fstream.ensure((size_t)off + 256));
+	HIPOK(E->fout.ensure(sizeof(FwdOut) * n));
+	HIPOK(E->aout.ensure(sizeof(AlignOutDev) * n));
+	HIPOK(E->scratch.ensure((size_t)n * scratch_cap));
+	hipError_t he = launch_build_stream(E->tcodes.as<uint8_t>(), E->fprobs.as<FwdProb>(), n, E->fstream.as<uint8_t>(), E->st);
+	if (he != hipSuccess) return fail(E, FASIM_E_HIP, "build_stream launch failed: %s", hipGetErrorString(he));
+	FwdLaunch L;
+	L.stream = E->fstream.as<uint8_t>(); L.probs = E->fprobs.as<FwdProb>(); L.task_first = E->ftasks.as<int32_t>(); L.ntask = ntask;
+	L.counter = E->counter.as<uint32_t>(); L.qcodes = E->q2.as<uint8_t>(); L.m = E->m; L.out = E->fout.as<FwdOut>();
+	{ TimedScope ts(E, 2); he = launch_align_fwd(L, E->st); }
+	if (he != hipSuccess) return fail(E, FASIM_E_HIP, "align_fwd launch failed: %s", hipGetErrorString(he));
+	{ TimedScope ts(E, 3);
+	he = launch_finish(E->tcodes.as<uint8_t>(), E->q2.as<uint8_t>(), E->fprobs.as<FwdProb>(), E->fout.as<FwdOut>(), n,
+		E->scratch.as<uint8_t>(), scratch_cap, E->aout.as<AlignOutDev>(), E->st); }
+	if (he != hipSuccess) return fail(E, FASIM_E_HIP, "finish launch failed: %s", hipGetErrorString(he));
+	std::vector<AlignOutDev> ao(n);
+	HIPOK(hipMemcpyAsync(ao.data(), E->aout.p, sizeof(AlignOutDev) * n, hipMemcpyDeviceToHost, E->st));
+	HIPOK(hipStreamSynchronize(E->st));
+	std::vector<int> redo;
+	for (int k = 0; k < n; k++) {
+		const AlignOutDev& a = ao[k];
+		if (a.status == 2 || a.status == 4 || a.status == 10 || a.status == 11) { redo.push_back(k); continue; }
+		AlignResult& r = out[k];
+		if (a.status != 0 || a.sw_score <= 0) { r.sw_score = 0; continue; }   // status 1/3: NULL from ssw_align -> sw_score 0
+		r.sw_score = a.sw_score; r.ref_begin = a.ref_begin; r.ref_end = a.ref_end; r.query_begin = a.query_begin; r.query_end = a.query_end;
+		r.cigar_len = a.cigar_len;
+		memcpy(r.cigar, a.cigar, sizeof(uint32_t) * a.cigar_len);
+	}
+	if (!redo.empty()) {
+		std::vector<WindowProb> W2(redo.size());
+		for (size_t i = 0; i < redo.size(); i++) W2[i] = W[redo[i]];
+		std::vector<AlignResult> r2;
+		rc = run_align(E, B, W2, r2, nullptr); if (rc) return rc;
+		for (size_t i = 0; i < redo.size(); i++) out[redo[i]] = r2[i];
+		if (stats) stats->align_word_reruns += (int64_t)redo.size();
+	}
+	return FASIM_OK;
+}
+
 // raw targets (letters) -> a UnitBatch whose codes use the given alphabet
 int load_raw_targets(fasim_engine* E, const char* targets, const int64_t* offsets, const int32_t* lens, int nprob,
 	bool stage1, UnitBatch& B)
@@ -484,6 +552,8 @@ int fasim_engine_create(int device, fasim_engine** out)
 	E->host_threads = env ? std::max(1, atoi(env)) : (int)std::min(32u, std::max(1u, hc));
 	const char* v1 = getenv("FASIM_SCAN_V1");
 	E->scan_v1 = v1 && atoi(v1) != 0;
+	const char* a1 = getenv("FASIM_ALIGN_V1");
+	E->align_v1 = a1 && atoi(a1) != 0;
 	*out = E;
 	return FASIM_OK;
 }
@@ -494,7 +564,8 @@ void fasim_engine_destroy(fasim_engine* e)
 	(void)hipSetDevice(e->device);
 	DevBuf* bufs[] = { &e->q1, &e->q2, &e->enc_lut, &e->counter, &e->dna, &e->seg_start, &e->seg_len, &e->enc_ids, &e->tcodes,
 		&e->colmax, &e->probs, &e->max_out, &e->unit_len, &e->stage1, &e->hits, &e->hits_total, &e->hit_off, &e->hit_cnt, &e->thr,
-		&e->ends, &e->bprobs, &e->bout, &e->scratch, &e->dna_res, &e->colmax16, &e->unit_ids, &e->flags, &e->stage1_in, &e->hits2 };
+		&e->ends, &e->bprobs, &e->bout, &e->scratch, &e->dna_res, &e->colmax16, &e->unit_ids, &e->flags, &e->stage1_in, &e->hits2,
+		&e->fprobs, &e->ftasks, &e->fstream, &e->fout, &e->aout };
 	for (auto& t : e->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
 	for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
 	for (DevBuf* b : bufs) b->release();
@@ -586,7 +657,7 @@ int fasim_align_batch(fasim_engine* E, const char* windows, const int64_t* offse
 	std::vector<WindowProb> W(nprob);
 	for (int i = 0; i < nprob; i++) { W[i].unit = i; W[i].t0 = 0; W[i].len = lens[i]; }
 	std::vector<AlignResult> res;
-	rc = run_align(E, B, W, res, nullptr); if (rc) return rc;
+	rc = run_align_v2(E, B, W, res, nullptr); if (rc) return rc;
 	for (int i = 0; i < nprob; i++) {
 		out[i].sw_score = res[i].sw_score; out[i].ref_begin = res[i].ref_begin; out[i].ref_end = res[i].ref_end;
 		out[i].query_begin = res[i].query_begin; out[i].query_end = res[i].query_end; out[i].cigar_len = res[i].cigar_len;
@@ -811,7 +882,7 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 				st.align_calls += (int64_t)W.size();
 				for (const WindowProb& w : W) st.cells_stage3 += (int64_t)E->m * w.len;
 				std::vector<AlignResult> res;
-				rc = run_align(E, B, W, res, &st); if (rc) return rc;
+				rc = run_align_v2(E, B, W, res, &st); if (rc) return rc;
 				for (size_t i = 0; i < who.size(); i++) {
 					CandState& x = cs[who[i]];
 					x.al = res[i];

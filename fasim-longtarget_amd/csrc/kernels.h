@@ -50,4 +50,14 @@ hipError_t launch_scan_post(const uint16_t* colmax16, const int32_t* unit_ids, i
 hipError_t launch_max16(const uint16_t* colmax16, const int32_t* unit_ids, int32_t nwork, const int32_t* unit_len,
 	int32_t tstride, int32_t* out, hipStream_t st);
 
+// ---- align.hip: stage 3 ---------------------------------------------------------------------------
+struct FwdLaunch {
+	const uint8_t* stream; const FwdProb* probs; const int32_t* task_first; int32_t ntask; uint32_t* counter;
+	const uint8_t* qcodes; int32_t m; FwdOut* out;
+};
+hipError_t launch_build_stream(const uint8_t* tcodes, const FwdProb* probs, int32_t nprob, uint8_t* stream, hipStream_t st);
+hipError_t launch_align_fwd(const FwdLaunch& L, hipStream_t st);     // hipErrorInvalidValue: query too long
+hipError_t launch_finish(const uint8_t* tcodes, const uint8_t* qcodes, const FwdProb* probs, const FwdOut* fwd, int32_t nprob,
+	uint8_t* scratch, int32_t scratch_cap, AlignOutDev* out, hipStream_t st);
+
 } // namespace fasim

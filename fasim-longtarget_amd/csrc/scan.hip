@@ -19,9 +19,10 @@
 // every unit in which the reference's layout-dependent behaviour cannot show: the column maxima are the
 // textbook ones up to the reference's overflow column (Q1, applied in k_scan_post) unless the signed
 // lazy-F exit (Q2, sswNew.cpp:369) can trigger.  Q2 needs an F value >= 132 to cross one of the 15 stripe
-// boundaries k*ceil(m/16) of the reference's striped layout; the kernel raises a per-column hazard bit
-// whenever that is possible (conservatively), and hazard units are re-run by the stripe-faithful kernel
-// (kernels.hip).  Zero-score pad rows (Q3) are part of the profile.
+// boundaries k*ceil(m/16) of the reference's striped layout.  The rows are laid out so that each of the
+// reference's 16 stripes is exactly 8 virtual lanes: the F entering virtual lane 8k IS the F crossing
+// boundary k, and the kernel raises a per-column hazard bit when it is >= 132.  Hazard units are re-run
+// by the stripe-faithful kernel (kernels.hip).  Zero-score pad rows (Q3) are part of the profile.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernels.h"
@@ -76,34 +77,33 @@ __global__ void __launch_bounds__(256) k_scan(ScanArgs a)
 		const int r = idx % SCAN_RS;
 		const int v = (idx / SCAN_RS) % 128;
 		const int t = idx / (SCAN_RS * 128);
-		const int row = v * RP + r;
+		// stripe-aligned layout: the reference's stripe s = rows [s*segLen, (s+1)*segLen) is spread over the 8
+		// virtual lanes 8s..8s+7, so every stripe boundary is a virtual-lane boundary
+		const int vq = a.seg_len16 / 8, vrem = a.seg_len16 % 8, vj = v & 7;
+		const int rows_v = vq + (vj < vrem ? 1 : 0);
+		const int row = (v >> 3) * a.seg_len16 + vj * vq + (vj < vrem ? vj : vrem) + r;
 		int sc = SCAN_DEAD;
-		if (r < RP) {
+		if (r < rows_v) {
 			if (row < a.m) sc = a.score[t * 5 + a.qcodes[row]];
-			else if (row < a.m_pad) sc = 0;
+			else sc = 0;                      // rows [m, 16*segLen) are the reference's zero-score pad rows (Q3)
 		}
 		*reinterpret_cast<int16_t*>(prof + t * SCAN_CODE_STRIDE + (v >> 1) * SCAN_LANE_STRIDE + (v & 1) * 48 + r * 2) = (int16_t)sc;
 	}
 	__syncthreads();
 
-	// ---- per-lane hazard constants: does a stripe boundary k*seg_len16 (k = 1..15) fall into my rows? --
-	// hb = 0xFFFF in a half that holds a boundary row; fthr = 131 + 4*offset (F_in >= 132 + 4*offset), else 0xFFFF
-	uint32_t hb = 0, fthr = 0xFFFFFFFFu;
+	// ---- per-lane constants ---------------------------------------------------------------------------
+	// fthr: a half whose virtual lane starts a stripe (v = 8k, k >= 1) sees F[b] of the boundary row b directly as
+	//       its incoming F; Q2 needs F[b] >= 132 (131 = "greater than" threshold), other halves never flag.
+	// act : 0xFFFF where the half owns RP rows, 0 where it owns RP-1 (its last register row is transparent)
+	uint32_t fthr = 0xFFFFFFFFu, act = 0;
 	for (int h = 0; h < 2; h++) {
 		const int v = 2 * lane + h;
-		const int lo = v * RP, hi = lo + RP;      // rows [lo, hi)
-		for (int k = 1; k < 16; k++) {
-			const int b = k * a.seg_len16;
-			if (b >= lo && b < hi && b < a.m_pad) {
-				hb |= 0xFFFFu << (16 * h);
-				const uint32_t cur = (fthr >> (16 * h)) & 0xFFFFu;
-				const uint32_t cand = 131u + 4u * (uint32_t)(b - lo);
-				if (cand < cur) fthr = (fthr & ~(0xFFFFu << (16 * h))) | (cand << (16 * h));
-			}
-		}
+		if ((v & 7) == 0 && v > 0) fthr = (fthr & ~(0xFFFFu << (16 * h))) | (131u << (16 * h));
+		const int vrem = a.seg_len16 % 8;
+		if (vrem == 0 || (v & 7) < vrem) act |= 0xFFFFu << (16 * h);
 	}
-	const v2u hbmask = __builtin_bit_cast(v2u, hb);
 	const v2u fthr2 = __builtin_bit_cast(v2u, fthr);
+	const v2u actm = __builtin_bit_cast(v2u, act);
 	const uint8_t* pl = prof + lane * SCAN_LANE_STRIDE;
 
 	for (;;) {
@@ -154,21 +154,28 @@ __global__ void __launch_bounds__(256) k_scan(ScanArgs a)
 						v2s h = hprev + s_from(sc);
 						h = __builtin_elementwise_max(h, as_s(E[r]));
 						h = __builtin_elementwise_max(h, as_s(f));
-						lmax = __builtin_elementwise_max(lmax, h);
 						H[r] = h;
 						const v2u ho = __builtin_elementwise_sub_sat(as_u(h), (v2u){ GAP_OPEN, GAP_OPEN });
 						E[r] = __builtin_elementwise_max(__builtin_elementwise_sub_sat(E[r], (v2u){ GAP_EXT, GAP_EXT }), ho);
-						f = __builtin_elementwise_max(__builtin_elementwise_sub_sat(f, (v2u){ GAP_EXT, GAP_EXT }), ho);
+						const v2u fnew = __builtin_elementwise_max(__builtin_elementwise_sub_sat(f, (v2u){ GAP_EXT, GAP_EXT }), ho);
+						if (r == RP - 1) {
+							// a half that owns only RP-1 rows passes F and its bottom H through unchanged
+							f = (fnew & actm) | (f & ~actm);
+							lmax = __builtin_elementwise_max(lmax, as_s(as_u(h) & actm));
+							if (RP > 1) hbot = to_int((as_u(h) & actm) | (as_u(H[RP > 1 ? RP - 2 : 0]) & ~actm));
+							else hbot = to_int(h);
+						} else {
+							f = fnew;
+							lmax = __builtin_elementwise_max(lmax, h);
+						}
 						hprev = hold;
 					}
 				}
 			}
-			hbot = to_int(H[RP - 1]);
 			fbot = to_int(f);
 			// running column maximum + hazard bit (bit 15) travelling with the column
-			const v2u hz_a = __builtin_elementwise_sub_sat(as_u(lmax), (v2u){ 147, 147 }) & hbmask;
 			const v2u hz_b = __builtin_elementwise_sub_sat(__builtin_bit_cast(v2u, recv_f), fthr2);
-			const v2u hz = __builtin_elementwise_min(hz_a | hz_b, (v2u){ 1, 1 }) << (v2u){ 15, 15 };
+			const v2u hz = __builtin_elementwise_min(hz_b, (v2u){ 1, 1 }) << (v2u){ 15, 15 };
 			const v2u cin = __builtin_bit_cast(v2u, recv_cm);
 			const v2u cval = __builtin_elementwise_max(cin & (v2u){ 0x7fff, 0x7fff }, as_u(lmax));
 			cm = to_int(cval | ((cin | hz) & (v2u){ 0x8000, 0x8000 }));
@@ -198,13 +205,17 @@ hipError_t launch_scan(const ScanLaunch& L, hipStream_t st)
 	a.counter = L.counter; a.qcodes = L.qcodes; a.m = L.m; a.m_pad = 16 * ((L.m + 15) / 16); a.seg_len16 = (L.m + 15) / 16;
 	for (int i = 0; i < 25; i++) a.score[i] = L.score[i];
 	a.colmax16 = L.colmax16;
-	const int rp = (a.m_pad + 127) / 128;
-	if (rp <= 8) return launch_scan_t<8>(a, st);
-	if (rp <= 12) return launch_scan_t<12>(a, st);
-	if (rp <= 16) return launch_scan_t<16>(a, st);
-	if (rp <= 20) return launch_scan_t<20>(a, st);
-	if (rp <= 22) return launch_scan_t<22>(a, st);
-	if (rp <= 24) return launch_scan_t<24>(a, st);
+	if (a.seg_len16 < 8) return hipErrorInvalidValue;      // tiny queries: striped kernels
+	// RP must be exactly ceil(segLen/8): every virtual lane then owns RP or RP-1 rows
+	switch ((a.seg_len16 + 7) / 8) {
+#define FASIM_SCAN_CASE(N) case N: return launch_scan_t<N>(a, st);
+	FASIM_SCAN_CASE(1) FASIM_SCAN_CASE(2) FASIM_SCAN_CASE(3) FASIM_SCAN_CASE(4) FASIM_SCAN_CASE(5) FASIM_SCAN_CASE(6)
+	FASIM_SCAN_CASE(7) FASIM_SCAN_CASE(8) FASIM_SCAN_CASE(9) FASIM_SCAN_CASE(10) FASIM_SCAN_CASE(11) FASIM_SCAN_CASE(12)
+	FASIM_SCAN_CASE(13) FASIM_SCAN_CASE(14) FASIM_SCAN_CASE(15) FASIM_SCAN_CASE(16) FASIM_SCAN_CASE(17) FASIM_SCAN_CASE(18)
+	FASIM_SCAN_CASE(19) FASIM_SCAN_CASE(20) FASIM_SCAN_CASE(21) FASIM_SCAN_CASE(22) FASIM_SCAN_CASE(23) FASIM_SCAN_CASE(24)
+#undef FASIM_SCAN_CASE
+	default: break;
+	}
 	return hipErrorInvalidValue;         // query longer than 3072 rows: caller uses the striped kernels
 }
 

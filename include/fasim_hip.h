@@ -93,7 +93,10 @@ typedef struct fasim_triplex {
 
 typedef struct fasim_scan_stats {
 	int64_t segments, segments_skipped, units;
-	int64_t candidates, align_calls, align_word_reruns, stage2_overflow_units, stage1_word_reruns;
+	int64_t candidates, align_calls;
+	int64_t align_word_reruns;          /* window alignments re-run on the stripe-faithful kernels (possible Q2,
+	                                       16-bit re-runs, undecided reverse passes)                              */
+	int64_t stage2_overflow_units, stage1_word_reruns;
 	int64_t logical_cells;              /* m * sum(len(segment)) * n_enc                  */
 	double  t_total_s, t_stage1_s, t_stage2_s, t_stage3_s, t_host_s;   /* host wall clock per phase       */
 	/* HIP-event time of the kernels, summed over launches on the engine's stream.  index: 0 k_scan (fused
