@@ -321,7 +321,8 @@ __device__ int reverse_pass(const uint8_t* __restrict__ tw /* window codes */, c
 
 __global__ void __launch_bounds__(64) k_finish(const uint8_t* __restrict__ tcodes, const uint8_t* __restrict__ qcodes,
 	const FwdProb* __restrict__ probs, const FwdOut* __restrict__ fwd, int32_t nprob, uint8_t* __restrict__ scratch,
-	int32_t scratch_cap, AlignOutDev* __restrict__ out)
+	int32_t scratch_cap, AlignOutDev* __restrict__ out, uint32_t* __restrict__ cigar_pool, uint32_t pool_cap,
+	uint32_t* __restrict__ pool_count)
 {
 	const int pi = blockIdx.x * blockDim.x + threadIdx.x;
 	if (pi >= nprob) return;
@@ -329,7 +330,9 @@ __global__ void __launch_bounds__(64) k_finish(const uint8_t* __restrict__ tcode
 	const FwdOut fo = fwd[pi];
 	AlignOutDev* o = out + pi;
 	o->sw_score = 0; o->ref_begin = 0; o->ref_end = fo.ref_end; o->query_begin = 0; o->query_end = fo.read_end; o->cigar_len = 0;
-	if (fo.flags != 0) { o->status = 10; return; }                 // possible Q2: stripe-faithful re-run
+	o->cigar_off = 0;
+	if (fo.flags != 0) { o->status = 10; return; }                 // possible Q2 in the forward pass: stripe-faithful re-run
+	if (fo.score >= 148) { o->status = 11; return; }               // an F >= 132 is possible in the reverse pass (its own stripes)
 	if (fo.score <= 0 || fo.ref_end < 0) { o->status = 0; return; }   // nothing aligned
 	uint8_t* my = scratch + (int64_t)pi * scratch_cap;
 	const uint8_t* tw = tcodes + pb.tbase;
@@ -426,18 +429,26 @@ __global__ void __launch_bounds__(64) k_finish(const uint8_t* __restrict__ tcode
 		if (op == 0) { if (l >= ALIGN_MAX_CIGAR) status = 4; else rc[l++] = cig(e + 1, 0); }
 		else { if (l + 2 > ALIGN_MAX_CIGAR) status = 4; else { rc[l++] = cig(e, op); rc[l++] = cig(1, 0); } }
 	}
+	if (status == 0) {
+		const uint32_t off = atomicAdd(pool_count, (uint32_t)l);
+		if ((uint64_t)off + (uint64_t)l > (uint64_t)pool_cap) status = 4;
+		else { o->cigar_off = off; for (int k = 0; k < l; k++) cigar_pool[off + k] = rc[l - 1 - k]; }
+	}
 	o->status = status;
 	if (status != 0) return;
 	o->sw_score = score;
 	o->cigar_len = l;
-	for (int k = 0; k < l; k++) o->cigar[k] = rc[l - 1 - k];
 }
 
 hipError_t launch_finish(const uint8_t* tcodes, const uint8_t* qcodes, const FwdProb* probs, const FwdOut* fwd, int32_t nprob,
-	uint8_t* scratch, int32_t scratch_cap, AlignOutDev* out, hipStream_t st)
+	uint8_t* scratch, int32_t scratch_cap, AlignOutDev* out, uint32_t* cigar_pool, uint32_t pool_cap, uint32_t* pool_count,
+	hipStream_t st)
 {
 	if (nprob <= 0) return hipSuccess;
-	hipLaunchKernelGGL(k_finish, dim3((nprob + 63) / 64), dim3(64), 0, st, tcodes, qcodes, probs, fwd, nprob, scratch, scratch_cap, out);
+	hipError_t err = hipMemsetAsync(pool_count, 0, sizeof(uint32_t), st);
+	if (err != hipSuccess) return err;
+	hipLaunchKernelGGL(k_finish, dim3((nprob + 63) / 64), dim3(64), 0, st, tcodes, qcodes, probs, fwd, nprob, scratch, scratch_cap, out,
+		cigar_pool, pool_cap, pool_count);
 	return hipGetLastError();
 }
 

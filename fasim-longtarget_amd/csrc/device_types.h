@@ -58,13 +58,12 @@ struct FwdProb {
 };
 struct FwdOut { int32_t score, ref_end, read_end, flags; };   // flags != 0: possible Q2 -> stripe-faithful re-run
 constexpr int ALIGN_MAX_CIGAR = 48;
-struct AlignOutDev {
+struct AlignOutDev {           // 32-byte header; the CIGAR ops go to a compact pool
 	int32_t sw_score, ref_begin, ref_end, query_begin, query_end;
 	int32_t status;       // 0 ok; 1 traceback error (reference returns NULL); 3 undefined behaviour in the reference;
-	                      // 2/4/10/11: re-run on the stripe-faithful path (scratch, cigar length, hazard, reverse pass undecided)
+	                      // 2/4/10/11: re-run on the stripe-faithful path (scratch, cigar pool, hazard, reverse pass undecided)
 	int32_t cigar_len;
-	uint32_t cigar[ALIGN_MAX_CIGAR];
-	int32_t pad;
+	uint32_t cigar_off;   // offset in the cigar pool
 };
 
 // packed 4-bit score table: entry q (0..5) of row t = score(t,q)+BIAS

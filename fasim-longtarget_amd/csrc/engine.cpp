@@ -58,7 +58,7 @@ struct fasim_engine {
 	ScoreLut lut1, lut2;
 	DevBuf q1, q2, enc_lut, counter, dna, seg_start, seg_len, enc_ids, tcodes, colmax, probs, max_out, unit_len,
 		stage1, hits, hits_total, hit_off, hit_cnt, thr, ends, bprobs, bout, scratch, colmax16, unit_ids, flags, stage1_in, hits2,
-		fprobs, ftasks, fstream, fout, aout;
+		fprobs, ftasks, fstream, fout, aout, cigpool, cigcount;
 	bool align_v1 = false;        // FASIM_ALIGN_V1=1: force the stripe-faithful kernels for stage 3
 	bool query_acgt = true;       // query holds only A,C,G,T: stage-1 and stage-2 scoring coincide on N-free segments
 	bool scan_v1 = false;         // FASIM_SCAN_V1=1: force the stripe-faithful kernels for stages 1 and 2
@@ -337,7 +337,7 @@ struct WindowProb { int unit, t0, len; };
 
 // a9-a11: ssw_align for a list of windows (forward + reverse on the GPU, 16-bit re-runs, banded traceback)
 int run_align(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, std::vector<AlignResult>& out,
-	fasim_scan_stats* stats)
+	std::vector<uint32_t>& cigars, fasim_scan_stats* stats)
 {
 	const int n = (int)W.size();
 	out.assign(n, AlignResult());
@@ -423,23 +423,27 @@ int run_align(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>
 		r.sw_score = bp[i].score; r.ref_begin = e.ref_begin; r.ref_end = e.ref_end;
 		r.query_begin = e.read_begin; r.query_end = e.read_end;
 		r.cigar_len = bo[i].cigar_len;
-		memcpy(r.cigar, bo[i].cigar, sizeof(uint32_t) * bo[i].cigar_len);
+		r.cigar_off = (uint32_t)cigars.size();
+		cigars.insert(cigars.end(), bo[i].cigar, bo[i].cigar + bo[i].cigar_len);
 	}
 	return FASIM_OK;
 }
 
-// a9-a11 through the systolic forward kernel + per-alignment finish kernel (align.hip); windows that may hit
-// the reference's layout-dependent behaviour are re-run by run_align() above.
-int run_align_v2(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, std::vector<AlignResult>& out,
-	fasim_scan_stats* stats)
+// ---- stage 3 through align.hip ---------------------------------------------------------------------
+bool align_v2_fits(const fasim_engine* E, const std::vector<WindowProb>& W)
+{
+	const int seg16 = (E->m + 15) / 16;
+	if (E->align_v1 || seg16 < 8 || seg16 > 192) return false;      // 128 virtual lanes x up to 24 rows
+	for (const WindowProb& w : W) if (w.len > 200 || w.len <= 0) return false;
+	return true;
+}
+
+// forward pass of every window (k_build_stream + k_align_fwd): score, ref_end, read_end, hazard flag
+int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, std::vector<FwdOut>& fo)
 {
 	const int n = (int)W.size();
-	if (!n) { out.clear(); return FASIM_OK; }
-	const int seg16 = (E->m + 15) / 16;
-	bool fits = !E->align_v1 && seg16 >= 8 && seg16 <= 192;      // 128 virtual lanes x up to 24 rows
-	if (fits) for (int k = 0; k < n; k++) if (W[k].len > 200 || W[k].len <= 0) { fits = false; break; }
-	if (!fits) return run_align(E, B, W, out, stats);
-	out.assign(n, AlignResult());
+	fo.resize(n);
+	if (!n) return FASIM_OK;
 	std::vector<FwdProb> probs(n);
 	int64_t off = 0;
 	for (int k = 0; k < n; k++) {
@@ -447,47 +451,95 @@ int run_align_v2(fasim_engine* E, const UnitBatch& B, const std::vector<WindowPr
 		off += W[k].len + 2;
 	}
 	if (off > 0x7fff0000ll) return fail(E, FASIM_E_UNSUPPORTED, "window stream of one round exceeds 2 GiB; lower FASIM_SEG_BATCH");
-	int per_task = std::max(8, std::min(64, n / 3072));
+	const int per_task = std::max(8, std::min(64, n / 3072));
 	std::vector<int32_t> tasks;
 	for (int k = 0; k < n; k += per_task) tasks.push_back(k);
 	tasks.push_back(n);
-	const int ntask = (int)tasks.size() - 1;
-	const int scratch_cap = 8192;
 	int rc = upload(E, E->fprobs, probs.data(), sizeof(FwdProb) * n); if (rc) return rc;
 	rc = upload(E, E->ftasks, tasks.data(), sizeof(int32_t) * tasks.size()); if (rc) return rc;
 	HIPOK(E->fstream.ensure((size_t)off + 256));
 	HIPOK(E->fout.ensure(sizeof(FwdOut) * n));
-	HIPOK(E->aout.ensure(sizeof(AlignOutDev) * n));
-	HIPOK(E->scratch.ensure((size_t)n * scratch_cap));
 	hipError_t he = launch_build_stream(E->tcodes.as<uint8_t>(), E->fprobs.as<FwdProb>(), n, E->fstream.as<uint8_t>(), E->st);
 	if (he != hipSuccess) return fail(E, FASIM_E_HIP, "build_stream launch failed: %s", hipGetErrorString(he));
 	FwdLaunch L;
-	L.stream = E->fstream.as<uint8_t>(); L.probs = E->fprobs.as<FwdProb>(); L.task_first = E->ftasks.as<int32_t>(); L.ntask = ntask;
-	L.counter = E->counter.as<uint32_t>(); L.qcodes = E->q2.as<uint8_t>(); L.m = E->m; L.out = E->fout.as<FwdOut>();
+	L.stream = E->fstream.as<uint8_t>(); L.probs = E->fprobs.as<FwdProb>(); L.task_first = E->ftasks.as<int32_t>();
+	L.ntask = (int)tasks.size() - 1; L.counter = E->counter.as<uint32_t>(); L.qcodes = E->q2.as<uint8_t>(); L.m = E->m;
+	L.out = E->fout.as<FwdOut>();
 	{ TimedScope ts(E, 2); he = launch_align_fwd(L, E->st); }
 	if (he != hipSuccess) return fail(E, FASIM_E_HIP, "align_fwd launch failed: %s", hipGetErrorString(he));
+	HIPOK(hipMemcpyAsync(fo.data(), E->fout.p, sizeof(FwdOut) * n, hipMemcpyDeviceToHost, E->st));
+	HIPOK(hipStreamSynchronize(E->st));
+	return FASIM_OK;
+}
+
+// reverse pass + banded traceback (k_finish) of windows whose forward result is known.
+// status[k]: 0 = result valid (sw_score 0 when nothing aligned); 1 = the reference's traceback fails (NULL);
+//            2 = must be decided by the stripe-faithful path
+int run_finish(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, const std::vector<FwdOut>& fo,
+	std::vector<AlignResult>& out, std::vector<uint32_t>& cigars, std::vector<char>& status)
+{
+	const int n = (int)W.size();
+	out.assign(n, AlignResult()); status.assign(n, 0);
+	if (!n) return FASIM_OK;
+	std::vector<FwdProb> probs(n);
+	for (int k = 0; k < n; k++) { probs[k].tbase = (int64_t)W[k].unit * B.tstride + W[k].t0; probs[k].len = W[k].len; probs[k].stream_off = 0; }
+	const int scratch_cap = 8192;
+	int rc = upload(E, E->fprobs, probs.data(), sizeof(FwdProb) * n); if (rc) return rc;
+	rc = upload(E, E->fout, fo.data(), sizeof(FwdOut) * n); if (rc) return rc;
+	HIPOK(E->aout.ensure(sizeof(AlignOutDev) * n));
+	HIPOK(E->scratch.ensure((size_t)n * scratch_cap));
+	const size_t pool_cap = (size_t)n * 12 + 4096;
+	HIPOK(E->cigpool.ensure(pool_cap * sizeof(uint32_t)));
+	HIPOK(E->cigcount.ensure(64));
+	hipError_t he;
 	{ TimedScope ts(E, 3);
 	he = launch_finish(E->tcodes.as<uint8_t>(), E->q2.as<uint8_t>(), E->fprobs.as<FwdProb>(), E->fout.as<FwdOut>(), n,
-		E->scratch.as<uint8_t>(), scratch_cap, E->aout.as<AlignOutDev>(), E->st); }
+		E->scratch.as<uint8_t>(), scratch_cap, E->aout.as<AlignOutDev>(), E->cigpool.as<uint32_t>(), (uint32_t)pool_cap,
+		E->cigcount.as<uint32_t>(), E->st); }
 	if (he != hipSuccess) return fail(E, FASIM_E_HIP, "finish launch failed: %s", hipGetErrorString(he));
 	std::vector<AlignOutDev> ao(n);
+	uint32_t pool_used = 0;
 	HIPOK(hipMemcpyAsync(ao.data(), E->aout.p, sizeof(AlignOutDev) * n, hipMemcpyDeviceToHost, E->st));
+	HIPOK(hipMemcpyAsync(&pool_used, E->cigcount.p, sizeof pool_used, hipMemcpyDeviceToHost, E->st));
 	HIPOK(hipStreamSynchronize(E->st));
-	std::vector<int> redo;
+	if (pool_used > pool_cap) pool_used = (uint32_t)pool_cap;
+	const uint32_t pool_base = (uint32_t)cigars.size();
+	cigars.resize((size_t)pool_base + pool_used);
+	if (pool_used) {
+		HIPOK(hipMemcpyAsync(cigars.data() + pool_base, E->cigpool.p, sizeof(uint32_t) * pool_used, hipMemcpyDeviceToHost, E->st));
+		HIPOK(hipStreamSynchronize(E->st));
+	}
 	for (int k = 0; k < n; k++) {
 		const AlignOutDev& a = ao[k];
-		if (a.status == 2 || a.status == 4 || a.status == 10 || a.status == 11) { redo.push_back(k); continue; }
+		if (a.status == 2 || a.status == 4 || a.status == 10 || a.status == 11) { status[k] = 2; continue; }
+		if (a.status == 1 || a.status == 3) { status[k] = 1; continue; }
 		AlignResult& r = out[k];
-		if (a.status != 0 || a.sw_score <= 0) { r.sw_score = 0; continue; }   // status 1/3: NULL from ssw_align -> sw_score 0
+		if (a.sw_score <= 0) { r.sw_score = 0; continue; }
 		r.sw_score = a.sw_score; r.ref_begin = a.ref_begin; r.ref_end = a.ref_end; r.query_begin = a.query_begin; r.query_end = a.query_end;
-		r.cigar_len = a.cigar_len;
-		memcpy(r.cigar, a.cigar, sizeof(uint32_t) * a.cigar_len);
+		r.cigar_len = a.cigar_len; r.cigar_off = pool_base + a.cigar_off;
 	}
+	return FASIM_OK;
+}
+
+// ssw_align for a list of windows: systolic forward pass + finish kernel; everything that may hit the reference's
+// layout-dependent behaviour is re-run by run_align()
+int run_align_v2(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, std::vector<AlignResult>& out,
+	std::vector<uint32_t>& cigars, fasim_scan_stats* stats)
+{
+	const int n = (int)W.size();
+	if (!n) { out.clear(); return FASIM_OK; }
+	if (!align_v2_fits(E, W)) return run_align(E, B, W, out, cigars, stats);
+	std::vector<FwdOut> fo;
+	int rc = run_fwd(E, B, W, fo); if (rc) return rc;
+	std::vector<char> status;
+	rc = run_finish(E, B, W, fo, out, cigars, status); if (rc) return rc;
+	std::vector<int> redo;
+	for (int k = 0; k < n; k++) { if (status[k] == 2) redo.push_back(k); else if (status[k] == 1) out[k].sw_score = 0; }
 	if (!redo.empty()) {
 		std::vector<WindowProb> W2(redo.size());
 		for (size_t i = 0; i < redo.size(); i++) W2[i] = W[redo[i]];
 		std::vector<AlignResult> r2;
-		rc = run_align(E, B, W2, r2, nullptr); if (rc) return rc;
+		rc = run_align(E, B, W2, r2, cigars, nullptr); if (rc) return rc;
 		for (size_t i = 0; i < redo.size(); i++) out[redo[i]] = r2[i];
 		if (stats) stats->align_word_reruns += (int64_t)redo.size();
 	}
@@ -565,7 +617,7 @@ void fasim_engine_destroy(fasim_engine* e)
 	DevBuf* bufs[] = { &e->q1, &e->q2, &e->enc_lut, &e->counter, &e->dna, &e->seg_start, &e->seg_len, &e->enc_ids, &e->tcodes,
 		&e->colmax, &e->probs, &e->max_out, &e->unit_len, &e->stage1, &e->hits, &e->hits_total, &e->hit_off, &e->hit_cnt, &e->thr,
 		&e->ends, &e->bprobs, &e->bout, &e->scratch, &e->dna_res, &e->colmax16, &e->unit_ids, &e->flags, &e->stage1_in, &e->hits2,
-		&e->fprobs, &e->ftasks, &e->fstream, &e->fout, &e->aout };
+		&e->fprobs, &e->ftasks, &e->fstream, &e->fout, &e->aout, &e->cigpool, &e->cigcount };
 	for (auto& t : e->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
 	for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
 	for (DevBuf* b : bufs) b->release();
@@ -657,11 +709,13 @@ int fasim_align_batch(fasim_engine* E, const char* windows, const int64_t* offse
 	std::vector<WindowProb> W(nprob);
 	for (int i = 0; i < nprob; i++) { W[i].unit = i; W[i].t0 = 0; W[i].len = lens[i]; }
 	std::vector<AlignResult> res;
-	rc = run_align_v2(E, B, W, res, nullptr); if (rc) return rc;
+	std::vector<uint32_t> cigars;
+	rc = run_align_v2(E, B, W, res, cigars, nullptr); if (rc) return rc;
 	for (int i = 0; i < nprob; i++) {
 		out[i].sw_score = res[i].sw_score; out[i].ref_begin = res[i].ref_begin; out[i].ref_end = res[i].ref_end;
-		out[i].query_begin = res[i].query_begin; out[i].query_end = res[i].query_end; out[i].cigar_len = res[i].cigar_len;
-		memcpy(out[i].cigar, res[i].cigar, sizeof(uint32_t) * res[i].cigar_len);
+		out[i].query_begin = res[i].query_begin; out[i].query_end = res[i].query_end;
+		out[i].cigar_len = std::min(res[i].cigar_len, 256);
+		if (out[i].cigar_len) memcpy(out[i].cigar, cigars.data() + res[i].cigar_off, sizeof(uint32_t) * out[i].cigar_len);
 	}
 	return FASIM_OK;
 }
@@ -856,40 +910,99 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 			st.t_stage2_s += now_s() - t0;
 			}
 
-			// ---- candidates (a7) and the window tries (a8) in up to 4 rounds
+			// ---- candidates (a7) and the window tries (a8).  fastSIM() decides on sw_score and ref_end only
+			//      (fastsim.h:218-235); both are known after the FORWARD pass (the reverse pass returns the same
+			//      score: sswNew.cpp:1518 takes the minimum), so up to four forward rounds run first and the reverse
+			//      pass + traceback (k_finish) run once, for the chosen try.  Candidates with a try that may hit
+			//      the reference's layout-dependent behaviour, or whose traceback fails in the reference (NULL ->
+			//      score 0 -> the loop would have continued), are replayed try by try on the stripe-faithful path.
 			t0 = now_s();
-			struct CandState { int unit; Cand c; int done; AlignResult al; int cut; AlignResult best; int bestcut; int flag; };
+			struct CandState { int unit; Cand c; AlignResult al, best; FwdOut fsel, fbest; int cut, bestcut; char done, flag, exact; };
+			std::vector<uint32_t> cigars;
 			std::vector<CandState> cs;
 			{
 				std::vector<Cand> tmp;
 				for (int u = 0; u < B.nunit; u++) {
 					pick_candidates(hits.data() + hoff[u], hcnt[u], tmp);
-					for (const Cand& c : tmp) { CandState x; x.unit = u; x.c = c; x.done = 0; x.cut = 0; x.bestcut = 0; x.flag = 0; cs.push_back(x); }
+					for (const Cand& c : tmp) { CandState x; memset(&x.fsel, 0, sizeof x.fsel); memset(&x.fbest, 0, sizeof x.fbest);
+						x.unit = u; x.c = c; x.done = 0; x.cut = 0; x.bestcut = 0; x.flag = 0; x.exact = 0; cs.push_back(x); }
 				}
 			}
 			st.candidates += (int64_t)cs.size();
-			for (int it = 0; it < 4; it++) {
-				std::vector<WindowProb> W; std::vector<int> who;
-				for (size_t k = 0; k < cs.size(); k++) {
-					if (cs[k].done) continue;
-					int cut;
-					if (!window_for_try(it, cs[k].c.score, cs[k].c.pos, &cut)) { cs[k].done = 1; continue; }
-					cs[k].cut = cut;
-					W.push_back({ cs[k].unit, cs[k].c.pos - cut + 1, cut });
-					who.push_back((int)k);
+			bool v2 = true;
+			{ std::vector<WindowProb> probe(1, WindowProb{ 0, 0, 1 }); v2 = align_v2_fits(E, probe); }
+			if (v2) {
+				for (int it = 0; it < 4; it++) {
+					std::vector<WindowProb> W; std::vector<int> who;
+					for (size_t k = 0; k < cs.size(); k++) {
+						if (cs[k].done) continue;
+						int cut;
+						if (!window_for_try(it, cs[k].c.score, cs[k].c.pos, &cut)) { cs[k].done = 1; continue; }
+						cs[k].cut = cut;
+						W.push_back({ cs[k].unit, cs[k].c.pos - cut + 1, cut });
+						who.push_back((int)k);
+					}
+					if (W.empty()) break;
+					st.align_calls += (int64_t)W.size();
+					for (const WindowProb& w : W) st.cells_stage3 += (int64_t)E->m * w.len;
+					std::vector<FwdOut> fo;
+					rc = run_fwd(E, B, W, fo); if (rc) return rc;
+					for (size_t i = 0; i < who.size(); i++) {
+						CandState& x = cs[who[i]];
+						const FwdOut& f = fo[i];
+						// f.flags: the forward pass may hit Q2.  score >= 148: the REVERSE pass (other stripe geometry) could;
+						// below 148 no F can reach 132, so the reverse pass returns exactly the forward score.
+						if (f.flags || f.score >= 148) { x.exact = 1; x.done = 1; continue; }
+						x.fsel = f;                                                                        // "last tried" so far
+						if (f.score >= x.c.score) { x.flag = 1; x.done = 1; continue; }                    // fastsim.h:218-221
+						if (f.score > x.fbest.score && f.ref_end == x.cut - 1) { x.fbest = f; x.bestcut = x.cut; x.flag = 2; }   // :222-235
+					}
 				}
-				if (W.empty()) break;
-				st.align_calls += (int64_t)W.size();
-				for (const WindowProb& w : W) st.cells_stage3 += (int64_t)E->m * w.len;
-				std::vector<AlignResult> res;
-				rc = run_align_v2(E, B, W, res, &st); if (rc) return rc;
+				// the chosen try of every candidate -> reverse pass + traceback
+				std::vector<WindowProb> W; std::vector<FwdOut> fsel; std::vector<int> who;
+				for (size_t k = 0; k < cs.size(); k++) {
+					CandState& x = cs[k];
+					if (x.exact) continue;
+					if (x.flag == 2) { x.fsel = x.fbest; x.cut = x.bestcut; }                              // fastsim.h:238-250
+					if (x.fsel.score <= 0) { x.al.sw_score = 0; continue; }
+					W.push_back({ x.unit, x.c.pos - x.cut + 1, x.cut }); fsel.push_back(x.fsel); who.push_back((int)k);
+				}
+				std::vector<AlignResult> res; std::vector<char> status;
+				rc = run_finish(E, B, W, fsel, res, cigars, status); if (rc) return rc;
 				for (size_t i = 0; i < who.size(); i++) {
 					CandState& x = cs[who[i]];
+					if (status[i] != 0) { x.exact = 1; continue; }
 					x.al = res[i];
-					if (x.al.sw_score > 0) st.cells_stage3 += (int64_t)(x.al.query_end + 1) * (x.al.ref_end - x.al.ref_begin + 1);   // reverse pass
-					if (x.al.sw_score >= x.c.score) { x.flag = 1; x.done = 1; continue; }                    // fastsim.h:218-221
-					if (x.al.sw_score > x.best.sw_score && x.al.ref_end == x.cut - 1) { x.best = x.al; x.bestcut = x.cut; x.flag = 2; }   // :222-235
+					st.cells_stage3 += (int64_t)(x.al.ref_end - x.al.ref_begin + 1) * (x.al.query_end - x.al.query_begin + 1);
 				}
+			}
+			// stripe-faithful replay (all candidates when the systolic kernels do not fit the query)
+			{
+				std::vector<int> ex;
+				for (size_t k = 0; k < cs.size(); k++) if (!v2 || cs[k].exact) { ex.push_back((int)k); cs[k].done = 0; cs[k].flag = 0; cs[k].best = AlignResult(); cs[k].al = AlignResult(); }
+				if (v2) st.align_word_reruns += (int64_t)ex.size();
+				for (int it = 0; it < 4 && !ex.empty(); it++) {
+					std::vector<WindowProb> W; std::vector<int> who;
+					for (int k : ex) {
+						if (cs[k].done) continue;
+						int cut;
+						if (!window_for_try(it, cs[k].c.score, cs[k].c.pos, &cut)) { cs[k].done = 1; continue; }
+						cs[k].cut = cut;
+						W.push_back({ cs[k].unit, cs[k].c.pos - cut + 1, cut });
+						who.push_back(k);
+					}
+					if (W.empty()) break;
+					if (!v2) { st.align_calls += (int64_t)W.size(); for (const WindowProb& w : W) st.cells_stage3 += (int64_t)E->m * w.len; }
+					std::vector<AlignResult> res;
+					rc = run_align(E, B, W, res, cigars, nullptr); if (rc) return rc;
+					for (size_t i = 0; i < who.size(); i++) {
+						CandState& x = cs[who[i]];
+						x.al = res[i];
+						if (x.al.sw_score >= x.c.score) { x.flag = 1; x.done = 1; continue; }
+						if (x.al.sw_score > x.best.sw_score && x.al.ref_end == x.cut - 1) { x.best = x.al; x.bestcut = x.cut; x.flag = 2; }
+					}
+				}
+				for (int k : ex) if (cs[k].flag == 2) { cs[k].al = cs[k].best; cs[k].cut = cs[k].bestcut; }
 			}
 			st.t_stage3_s += now_s() - t0;
 
@@ -915,11 +1028,10 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 						const bool acgtn = seg_acgtn[s] != 0;
 						for (size_t k = first[u]; k < first[u + 1]; k++) {
 							CandState& x = cs[k];
-							AlignResult al = x.al; int cut = x.cut;
-							if (x.flag == 2) { al = x.best; cut = x.bestcut; }                                  // fastsim.h:238-250
-							if (al.sw_score == 0) continue;                                                    // :253
+							AlignResult al = x.al; const int cut = x.cut;
+							if (al.sw_score == 0) continue;                                                    // fastsim.h:253
 							al.ref_begin += x.c.pos - cut + 1; al.ref_end += x.c.pos - cut + 1;                // :254-255
-							convert_triplex(al, E->rna, seg, slen[s], enc, dna_start, p, mine, acgtn);
+							convert_triplex(al, cigars.data() + al.cigar_off, E->rna, seg, slen[s], enc, dna_start, p, mine, acgtn);
 						}
 						dedup_top(mine, p, per_unit[u]);
 						for (HostTriplex& t : per_unit[u]) { t.seg = (int)sidx[s]; t.enc = enc; }

@@ -160,7 +160,7 @@ bool only_acgtn(const char* seg, int n)
 	return true;
 }
 
-void convert_triplex(const AlignResult& al, const std::string& rna, const char* seg, int n, int enc,
+void convert_triplex(const AlignResult& al, const uint32_t* cigar, const std::string& rna, const char* seg, int n, int enc,
 	long dna_start, const fasim_params& p, std::vector<HostTriplex>& list, bool seg_acgtn)
 {
 	const EncInfo e = enc_info(enc);
@@ -180,7 +180,7 @@ void convert_triplex(const AlignResult& al, const std::string& rna, const char* 
 	std::string tgt_al, tts, tfo;
 	int q = al.ref_begin, r = al.query_begin;
 	for (int k = 0; k < al.cigar_len; k++) {
-		const uint32_t len = al.cigar[k] >> 4, op = al.cigar[k] & 0xf;
+		const uint32_t len = cigar[k] >> 4, op = cigar[k] & 0xf;
 		for (uint32_t t = 0; t < len; t++) {
 			if (op == 1) { tgt_al.push_back('-'); tts.push_back('-'); tfo.push_back(rna[r++]); }
 			else {

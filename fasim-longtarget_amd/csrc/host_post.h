@@ -20,10 +20,10 @@ bool same_seq(const char* seg, int n);
 struct Cand { int score, pos; };
 void pick_candidates(const uint32_t* hits, int nhits, std::vector<Cand>& out);   // hits = (pos<<8)|score, ascending pos
 
-struct AlignResult {
+struct AlignResult {            // CIGAR ops live in a pool owned by the caller: pool[cigar_off .. cigar_off+cigar_len)
 	int sw_score = 0, ref_begin = 0, ref_end = 0, query_begin = 0, query_end = 0;
 	int cigar_len = 0;
-	uint32_t cigar[62];
+	uint32_t cigar_off = 0;
 };
 
 // window length tried at iteration `it` (0..3) for a candidate (fastsim.h:204-211); returns false when the
@@ -40,7 +40,7 @@ struct HostTriplex {
 };
 
 // convertMyTriplex (fastsim.h:291-414): appends to `list` when nt >= ntMin
-void convert_triplex(const AlignResult& al, const std::string& rna, const char* seg, int n, int enc,
+void convert_triplex(const AlignResult& al, const uint32_t* cigar, const std::string& rna, const char* seg, int n, int enc,
 	long dna_start, const fasim_params& p, std::vector<HostTriplex>& list, bool seg_acgtn);
 bool only_acgtn(const char* seg, int n);
 // tail of fastSIM (fastsim.h:273-288): sort/unique/sort/unique/sort, top 50, identity/stability/nt filter
