@@ -200,6 +200,8 @@ def main():
             "executed_gcells_per_s": round((agg["cells_stage1"] + agg["cells_stage2"] + agg["cells_stage3"]) / (tmax) / 1e9 * 1.0, 3),
             "phase_wall_s": {k: round(agg[k], 3) for k in ("t_stage1_s", "t_stage2_s", "t_stage3_s", "t_host_s", "t_total_s")},
             "kernel_ms": {KERNEL_NAMES[i]: round(kms[i], 2) for i in range(5)},
+            "counts": {k: int(agg[k]) for k in ("segments", "units", "candidates", "align_calls", "hazard_units", "rev_exact",
+                                                "align_word_reruns", "stage2_overflow_units")},
             "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                          "avg_launch_ms": round(avg_ms, 3), "launches": int(launches),

@@ -118,6 +118,8 @@ __global__ void __launch_bounds__(256) k_align_fwd(FwdArgs a)
 	}
 	const v2u fthr2 = u_from((int)fthr);
 	const v2u actm = u_from((int)act);
+	const v2u startm = (v2u){ (unsigned short)(((2 * lane) & 7) == 0 && lane > 0 ? 0xFFFF : 0), 0 };
+	const bool lvl2 = a.seg_len16 >= 96;
 	const uint8_t* pl = prof + lane * AL_LANE_STRIDE;
 	// (31 - r) tags for the row keys, and the base of the global-row key of my two virtual lanes
 	const int kbase_lo = 0xFFFF - row0[0] - 31, kbase_hi = 0xFFFF - row0[1] - 31;
@@ -138,7 +140,7 @@ __global__ void __launch_bounds__(256) k_align_fwd(FwdArgs a)
 #pragma unroll
 		for (int r = 0; r < RP; r++) { H[r] = (v2s){ 0, 0 }; E[r] = (v2u){ 0, 0 }; }
 		int tc = (CODE_VOID << 16) | CODE_VOID;
-		int hbot = 0, fbot = 0, recv_h_last = 0;
+		int hbot = 0, fbot = 0, recv_h_last = 0, fpo = 0;
 		uint32_t klo = 0, khi = 0;           // (colmax << 16) | (0xFFFF - row) of my two virtual lanes' columns
 		int chunk = CODE_VOID;
 		// pipe-end state (meaningful in lane 63)
@@ -153,6 +155,7 @@ __global__ void __launch_bounds__(256) k_align_fwd(FwdArgs a)
 			tc = vshift2(tc, newcode << 16);
 			const int recv_h = vshift2(hbot, 0);
 			const int recv_f = vshift2(fbot, 0);
+			const int recv_fp = vshift2(fpo, 0);
 			const uint32_t kup = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)khi, 0x138, 0xf, 0xf, false);
 			const uint32_t kin_lo = kup, kin_hi = klo;       // from virtual lane v-1 (same column, one step ago)
 			const int t_lo = tc & 7, t_hi = (tc >> 16) & 7;
@@ -199,7 +202,32 @@ __global__ void __launch_bounds__(256) k_align_fwd(FwdArgs a)
 			}
 			fbot = a_i(f);
 			// hazard (possible Q2): the F entering a stripe-starting virtual lane is >= 132
-			const v2u hz_b = __builtin_elementwise_sub_sat(u_from(recv_f), fthr2);
+			// (same refined Q2 test as scan.hip, on values scaled by 32; void columns carry no F)
+			v2u hz_b = __builtin_elementwise_sub_sat(u_from(recv_f), fthr2);
+			fpo = 0;
+			if (lvl2) {
+				const v2u fpraw = ((u_from(recv_f) & startm) | (u_from(recv_fp) & ~startm)) & ~isvoid;
+				const v2u fp_in = fpraw & (v2u){ 0x7fff, 0x7fff };
+				const v2u arm_in = (fpraw >> (v2u){ 15, 15 }) & ~startm;
+				const v2u hot = __builtin_elementwise_sub_sat(fp_in, (v2u){ 132 * AL_SCALE - 1, 132 * AL_SCALE - 1 }) | __builtin_elementwise_min(arm_in, fp_in);
+				hz_b = (v2u){ 0, 0 };
+				if (__builtin_amdgcn_ballot_w64(a_i(hot) != 0) != 0ull) {
+					v2u fp = fp_in, arm = arm_in, acc = (v2u){ 0, 0 };
+#pragma unroll
+					for (int r = 0; r < RP; r++) {
+						const v2u ge = __builtin_elementwise_sub_sat(fp, (v2u){ 132 * AL_SCALE - 1, 132 * AL_SCALE - 1 });
+						v2u lt = __builtin_elementwise_sub_sat((v2u){ 144 * AL_SCALE, 144 * AL_SCALE }, a_u(H[r]));
+						v2u eq = __builtin_elementwise_sub_sat((v2u){ 1, 1 }, __builtin_elementwise_sub_sat(a_u(H[r]), fp));
+						v2u nfp = __builtin_elementwise_sub_sat(fp, (v2u){ GAP_EXT * AL_SCALE, GAP_EXT * AL_SCALE });
+						if (r == RP - 1) { lt &= actm; eq &= actm; nfp = (nfp & actm) | (fp & ~actm); }
+						acc = __builtin_elementwise_max(acc, __builtin_elementwise_min(__builtin_elementwise_min(eq, fp), arm));
+						arm = __builtin_elementwise_max(arm, __builtin_elementwise_min(__builtin_elementwise_min(ge, lt), (v2u){ 1, 1 }));
+						fp = nfp;
+					}
+					hz_b = acc;
+					fpo = a_i(fp | (arm << (v2u){ 15, 15 }));
+				}
+			}
 			const v2u hzb = __builtin_elementwise_min(hz_b, (v2u){ 1, 1 }) << (v2u){ 4, 4 };
 			tc |= a_i(hzb);
 			// per-column (max, smallest row) keys
@@ -221,7 +249,7 @@ __global__ void __launch_bounds__(256) k_align_fwd(FwdArgs a)
 					if (tag & TAG_LAST) {
 						FwdOut o;
 						o.score = runmax; o.ref_end = end_ref; o.read_end = end_read < a.m - 1 ? end_read : a.m - 1;
-						o.flags = hzflag;
+						o.flags = hzflag; o.ref_begin = 0; o.read_begin = 0;
 						a.out[pidx] = o;
 						pidx++; cidx = 0; runmax = 0; end_ref = -1; end_read = 0; hzflag = 0; over = 0;
 					}
@@ -331,13 +359,14 @@ __global__ void __launch_bounds__(64) k_finish(const uint8_t* __restrict__ tcode
 	AlignOutDev* o = out + pi;
 	o->sw_score = 0; o->ref_begin = 0; o->ref_end = fo.ref_end; o->query_begin = 0; o->query_end = fo.read_end; o->cigar_len = 0;
 	o->cigar_off = 0;
-	if (fo.flags != 0) { o->status = 10; return; }                 // possible Q2 in the forward pass: stripe-faithful re-run
-	if (fo.score >= 148) { o->status = 11; return; }               // an F >= 132 is possible in the reverse pass (its own stripes)
+	if (fo.flags & 1) { o->status = 10; return; }                  // possible Q2 in the forward pass: stripe-faithful re-run
 	if (fo.score <= 0 || fo.ref_end < 0) { o->status = 0; return; }   // nothing aligned
 	uint8_t* my = scratch + (int64_t)pi * scratch_cap;
 	const uint8_t* tw = tcodes + pb.tbase;
-	int ref_begin = 0, read_begin = 0;
-	{
+	int ref_begin = fo.ref_begin, read_begin = fo.read_begin;
+	if (!(fo.flags & 2)) {
+		// below 148 no F of the reverse pass can reach 132, so the signed lazy-F exit (Q2) cannot fire there
+		if (fo.score >= 148) { o->status = 11; return; }
 		int32_t* Gp = reinterpret_cast<int32_t*>(my);
 		int32_t* Ep = Gp + G_ROWS;
 		if (reverse_pass(tw, qcodes, fo.score, fo.ref_end, fo.read_end, Gp, Ep, &ref_begin, &read_begin)) { o->status = 11; return; }

@@ -19,6 +19,8 @@ struct StripedProb {
 	int32_t ref_len;   // number of columns
 	int32_t q_len;     // number of query rows (forward pass)
 	int32_t unit;      // output slot / provenance
+	int32_t aux;       // MODE_REV: the forward score the reverse pass terminates on
+	int32_t pad;
 };
 
 // result of the forward+reverse passes of ssw_align (sswNew.cpp:1446-1525)
@@ -56,7 +58,9 @@ struct FwdProb {
 	int32_t len;          // window length L
 	int32_t stream_off;   // offset of the window's first (void) byte in the column stream
 };
-struct FwdOut { int32_t score, ref_end, read_end, flags; };   // flags != 0: possible Q2 -> stripe-faithful re-run
+// flags bit 0: possible Q2 in the forward pass -> stripe-faithful re-run; bit 1: (ref_begin, read_begin) already hold
+// the result of an exact reverse pass and `score` is min(forward, reverse)
+struct FwdOut { int32_t score, ref_end, read_end, flags, ref_begin, read_begin; };
 constexpr int ALIGN_MAX_CIGAR = 48;
 struct AlignOutDev {           // 32-byte header; the CIGAR ops go to a compact pool
 	int32_t sw_score, ref_begin, ref_end, query_begin, query_end;

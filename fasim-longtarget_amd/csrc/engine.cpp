@@ -156,7 +156,7 @@ std::vector<StripedProb> whole_unit_probs(const UnitBatch& B, int m, const std::
 	v.reserve(n);
 	for (int k = 0; k < n; k++) {
 		const int u = subset ? (*subset)[k] : k;
-		StripedProb p; p.tbase = (int64_t)u * B.tstride; p.t0 = 0; p.ref_len = B.unit_len[u]; p.q_len = m; p.unit = u;
+		StripedProb p; p.tbase = (int64_t)u * B.tstride; p.t0 = 0; p.ref_len = B.unit_len[u]; p.q_len = m; p.unit = u; p.aux = 0; p.pad = 0;
 		v.push_back(p);
 	}
 	return v;
@@ -345,7 +345,7 @@ int run_align(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>
 	std::vector<StripedProb> probs(n);
 	for (int k = 0; k < n; k++) {
 		probs[k].tbase = (int64_t)W[k].unit * B.tstride; probs[k].t0 = W[k].t0; probs[k].ref_len = W[k].len;
-		probs[k].q_len = E->m; probs[k].unit = k;
+		probs[k].q_len = E->m; probs[k].unit = k; probs[k].aux = 0; probs[k].pad = 0;
 	}
 	HIPOK(E->ends.ensure(sizeof(AlignEnds) * n));
 	int rc = run_striped(E, MODE_ALIGN, false, probs, false, E->tcodes.as<uint8_t>(), E->m);
@@ -472,6 +472,35 @@ int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& 
 	return FASIM_OK;
 }
 
+// exact (stripe-faithful) reverse pass for windows whose forward result is exact but whose score (>= 148) would allow
+// the signed lazy-F exit in the reverse pass.  Fills fo[k].score = min(forward, reverse), ref_begin, read_begin, flag 2;
+// flag 1 is set where the result cannot be used (caller replays the candidate).
+int run_rev_exact(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, std::vector<FwdOut>& fo,
+	const std::vector<int>& idx)
+{
+	const int n = (int)idx.size();
+	if (!n) return FASIM_OK;
+	std::vector<StripedProb> probs(n);
+	for (int i = 0; i < n; i++) {
+		const int k = idx[i];
+		probs[i].tbase = (int64_t)W[k].unit * B.tstride; probs[i].t0 = W[k].t0; probs[i].ref_len = fo[k].ref_end + 1;
+		probs[i].q_len = fo[k].read_end + 1; probs[i].unit = i; probs[i].aux = fo[k].score; probs[i].pad = 0;
+	}
+	HIPOK(E->ends.ensure(sizeof(AlignEnds) * n));
+	int rc = run_striped(E, MODE_REV, false, probs, false, E->tcodes.as<uint8_t>(), E->m); if (rc) return rc;
+	std::vector<AlignEnds> ends(n);
+	HIPOK(hipMemcpyAsync(ends.data(), E->ends.p, sizeof(AlignEnds) * n, hipMemcpyDeviceToHost, E->st));
+	HIPOK(hipStreamSynchronize(E->st));
+	for (int i = 0; i < n; i++) {
+		FwdOut& f = fo[idx[i]];
+		const AlignEnds& e = ends[i];
+		if (e.ref_begin < 0 || e.read_begin < 0 || e.score_rev >= 255) { f.flags |= 1; continue; }
+		f.score = e.score_rev < f.score ? e.score_rev : f.score;          // sswNew.cpp:1518
+		f.ref_begin = e.ref_begin; f.read_begin = e.read_begin; f.flags |= 2;
+	}
+	return FASIM_OK;
+}
+
 // reverse pass + banded traceback (k_finish) of windows whose forward result is known.
 // status[k]: 0 = result valid (sw_score 0 when nothing aligned); 1 = the reference's traceback fails (NULL);
 //            2 = must be decided by the stripe-faithful path
@@ -531,6 +560,11 @@ int run_align_v2(fasim_engine* E, const UnitBatch& B, const std::vector<WindowPr
 	if (!align_v2_fits(E, W)) return run_align(E, B, W, out, cigars, stats);
 	std::vector<FwdOut> fo;
 	int rc = run_fwd(E, B, W, fo); if (rc) return rc;
+	{
+		std::vector<int> rv;
+		for (int k = 0; k < n; k++) if (!fo[k].flags && fo[k].score >= 148 && fo[k].score < 255 - BIAS) rv.push_back(k);
+		rc = run_rev_exact(E, B, W, fo, rv); if (rc) return rc;
+	}
 	std::vector<char> status;
 	rc = run_finish(E, B, W, fo, out, cigars, status); if (rc) return rc;
 	std::vector<int> redo;
@@ -818,7 +852,9 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 
 		const int tstride = (p.cutLength + 15) & ~15;
 		// batch size: bounded by memory for tcodes+colmax and by the stage-3 record volume
-		int64_t seg_batch = std::max<int64_t>(1, std::min<int64_t>(512, ((int64_t)3 << 30) / ((int64_t)2 * nenc * tstride)));
+		// ~2048 segments x 48 encodings per batch: amortises launch/transfer overheads and the latency floor of the
+		// stripe-faithful re-runs (one 16-lane group per hazard unit); bounded by memory (4 B per target column)
+		int64_t seg_batch = std::max<int64_t>(1, std::min<int64_t>(2048, ((int64_t)24 << 30) / ((int64_t)4 * nenc * tstride)));
 		const char* envb = getenv("FASIM_SEG_BATCH");
 		if (envb) seg_batch = std::max(1, atoi(envb));
 
@@ -947,12 +983,20 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 					for (const WindowProb& w : W) st.cells_stage3 += (int64_t)E->m * w.len;
 					std::vector<FwdOut> fo;
 					rc = run_fwd(E, B, W, fo); if (rc) return rc;
+					{
+						// score >= 148: the REVERSE pass (its own stripe geometry) could hit Q2 -> exact reverse pass now,
+						// so that sw_score = min(forward, reverse) is known before the decision
+						std::vector<int> rv;
+						for (size_t i = 0; i < fo.size(); i++) if (!fo[i].flags && fo[i].score >= 148 && fo[i].score < 255 - BIAS) rv.push_back((int)i);
+						rc = run_rev_exact(E, B, W, fo, rv); if (rc) return rc;
+						st.rev_exact += (int64_t)rv.size();
+					}
 					for (size_t i = 0; i < who.size(); i++) {
 						CandState& x = cs[who[i]];
 						const FwdOut& f = fo[i];
-						// f.flags: the forward pass may hit Q2.  score >= 148: the REVERSE pass (other stripe geometry) could;
-						// below 148 no F can reach 132, so the reverse pass returns exactly the forward score.
-						if (f.flags || f.score >= 148) { x.exact = 1; x.done = 1; continue; }
+						// flag 1: the forward pass may hit Q2 (or the exact reverse pass was unusable); scores >= 251 go through
+						// the reference's 16-bit kernels: both are replayed on the stripe-faithful path
+						if ((f.flags & 1) || (!(f.flags & 2) && f.score >= 148)) { x.exact = 1; x.done = 1; continue; }
 						x.fsel = f;                                                                        // "last tried" so far
 						if (f.score >= x.c.score) { x.flag = 1; x.done = 1; continue; }                    // fastsim.h:218-221
 						if (f.score > x.fbest.score && f.ref_end == x.cut - 1) { x.fbest = f; x.bestcut = x.cut; x.flag = 2; }   // :222-235

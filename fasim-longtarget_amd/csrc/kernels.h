@@ -5,7 +5,7 @@
 
 namespace fasim {
 
-enum StripedMode { MODE_PRE = 0, MODE_MAX1 = 1, MODE_ALIGN = 2 };
+enum StripedMode { MODE_PRE = 0, MODE_MAX1 = 1, MODE_ALIGN = 2, MODE_REV = 3 };
 
 struct StripedLaunch {
 	const uint8_t* tcodes;      // device: target codes

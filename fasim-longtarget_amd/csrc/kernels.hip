@@ -233,6 +233,11 @@ __global__ void __launch_bounds__(64) k_striped(StripedArgs a)
 			dir = 0; qrev = false; terminate = WORD ? 65535 : 255;
 			phase = 0; setup = true;
 			res.score_fwd = res.ref_end = res.read_end = res.score_rev = res.ref_begin = res.read_begin = 0;
+			if constexpr (MODE == MODE_REV) {
+				// reverse pass only (sswNew.cpp:1508-1516): the forward result is known and exact
+				dir = 1; qrev = true; terminate = pb.aux; phase = 1;
+				res.score_fwd = pb.aux; res.ref_end = refLen - 1; res.read_end = qlen - 1;
+			}
 		}
 		if (setup) {
 			// stripe geometry of this pass: segLen = ceil(qlen / P) (sswNew.cpp:279, 911)
@@ -302,7 +307,7 @@ __global__ void __launch_bounds__(64) k_striped(StripedArgs a)
 				if (s == 0) a.max_out[unit] = score;
 				phase = -1;
 			} else {
-				if (phase == 0) {
+				if (MODE == MODE_ALIGN && phase == 0) {
 					res.score_fwd = score;
 					res.ref_end = end_ref;
 					res.read_end = (maxv == 0) ? 0 : end_read;
@@ -366,6 +371,8 @@ hipError_t launch_striped(StripedMode mode, bool word, bool quirk, const Striped
 		return word ? launch_striped_t<MODE_MAX1, true, false>(a, st) : launch_striped_t<MODE_MAX1, false, false>(a, st);
 	case MODE_ALIGN:
 		return word ? launch_striped_t<MODE_ALIGN, true, false>(a, st) : launch_striped_t<MODE_ALIGN, false, true>(a, st);
+	case MODE_REV:
+		return launch_striped_t<MODE_REV, false, true>(a, st);      // byte mode only (forward score < 251)
 	}
 	(void)quirk;
 	return hipErrorInvalidValue;

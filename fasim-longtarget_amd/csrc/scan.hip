@@ -104,6 +104,10 @@ __global__ void __launch_bounds__(256) k_scan(ScanArgs a)
 	}
 	const v2u fthr2 = __builtin_bit_cast(v2u, fthr);
 	const v2u actm = __builtin_bit_cast(v2u, act);
+	// stripe-start halves (v = 8k, k >= 1) take the crossing F as the start of a propagation chain
+	const v2u startm = (v2u){ (unsigned short)(((2 * lane) & 7) == 0 && lane > 0 ? 0xFFFF : 0), 0 };
+	// the refined test needs F to die inside one stripe (F <= 234 decays by 4 per row)
+	const bool lvl2 = a.seg_len16 >= 96;
 	const uint8_t* pl = prof + lane * SCAN_LANE_STRIDE;
 
 	for (;;) {
@@ -120,7 +124,7 @@ __global__ void __launch_bounds__(256) k_scan(ScanArgs a)
 #pragma unroll
 		for (int r = 0; r < RP; r++) { H[r] = (v2s){ 0, 0 }; E[r] = (v2u){ 0, 0 }; }
 		int tc = 0x00040004;          // target codes of my two halves (N = neutral while the pipeline fills)
-		int hbot = 0, fbot = 0, cm = 0, recv_h_last = 0;
+		int hbot = 0, fbot = 0, cm = 0, recv_h_last = 0, fpo = 0;
 		int chunk = CODE_N;
 		const int nsteps = n + 127;
 		for (int step = 0; step < nsteps; step++) {
@@ -134,6 +138,7 @@ __global__ void __launch_bounds__(256) k_scan(ScanArgs a)
 			const int recv_h = vshift(hbot, 0);
 			const int recv_f = vshift(fbot, 0);
 			const int recv_cm = vshift(cm, 0);
+			const int recv_fp = vshift(fpo, 0);
 			const int t_lo = tc & 0xff, t_hi = (tc >> 16) & 0xff;
 			const uint8_t* pa = pl + t_lo * SCAN_CODE_STRIDE;
 			const uint8_t* pb = pl + t_hi * SCAN_CODE_STRIDE + 48;
@@ -173,8 +178,37 @@ __global__ void __launch_bounds__(256) k_scan(ScanArgs a)
 				}
 			}
 			fbot = to_int(f);
-			// running column maximum + hazard bit (bit 15) travelling with the column
-			const v2u hz_b = __builtin_elementwise_sub_sat(__builtin_bit_cast(v2u, recv_f), fthr2);
+			// ---- Q2 hazard.  The reference's lazy-F loop leaves early (signed compare, sswNew.cpp:369) only while a
+			// stripe's propagated boundary value Fp = F[b] - 4j is >= 132 and the H it has just corrected is < 144
+			// (then vF >= 128 reads as negative, vH < 128 as positive).  fp = F crossing a stripe start, carried down
+			// the rows of the stripe; the row test runs only in the (rare) steps where some lane holds fp >= 132.
+			v2u hz_b = __builtin_elementwise_sub_sat(__builtin_bit_cast(v2u, recv_f), fthr2);     // F[b] >= 132
+			fpo = 0;
+			if (lvl2) {
+				// fpo halves: bits 0..14 = propagated value, bit 15 = "an early exit was possible at an earlier row"
+				const v2u fpraw = (__builtin_bit_cast(v2u, recv_f) & startm) | (__builtin_bit_cast(v2u, recv_fp) & ~startm);
+				const v2u fp_in = fpraw & (v2u){ 0x7fff, 0x7fff };
+				const v2u arm_in = (fpraw >> (v2u){ 15, 15 }) & ~startm;
+				const v2u hot = __builtin_elementwise_sub_sat(fp_in, (v2u){ 131, 131 }) | __builtin_elementwise_min(arm_in, fp_in);
+				hz_b = (v2u){ 0, 0 };
+				if (__builtin_amdgcn_ballot_w64(to_int(hot) != 0) != 0ull) {
+					v2u fp = fp_in, arm = arm_in, acc = (v2u){ 0, 0 };
+#pragma unroll
+					for (int r = 0; r < RP; r++) {
+						const v2u ge = __builtin_elementwise_sub_sat(fp, (v2u){ 131, 131 });                  // Fp >= 132
+						v2u lt = __builtin_elementwise_sub_sat((v2u){ 144, 144 }, as_u(H[r]));               // H < 144
+						// a deviation shows only where, after a possible early exit, H is exactly the propagated value
+						v2u eq = __builtin_elementwise_sub_sat((v2u){ 1, 1 }, __builtin_elementwise_sub_sat(as_u(H[r]), fp));
+						v2u nfp = __builtin_elementwise_sub_sat(fp, (v2u){ GAP_EXT, GAP_EXT });
+						if (r == RP - 1) { lt &= actm; eq &= actm; nfp = (nfp & actm) | (fp & ~actm); }
+						acc = __builtin_elementwise_max(acc, __builtin_elementwise_min(__builtin_elementwise_min(eq, fp), arm));
+						arm = __builtin_elementwise_max(arm, __builtin_elementwise_min(__builtin_elementwise_min(ge, lt), (v2u){ 1, 1 }));
+						fp = nfp;
+					}
+					hz_b = acc;
+					fpo = to_int(fp | (arm << (v2u){ 15, 15 }));
+				}
+			}
 			const v2u hz = __builtin_elementwise_min(hz_b, (v2u){ 1, 1 }) << (v2u){ 15, 15 };
 			const v2u cin = __builtin_bit_cast(v2u, recv_cm);
 			const v2u cval = __builtin_elementwise_max(cin & (v2u){ 0x7fff, 0x7fff }, as_u(lmax));

@@ -106,6 +106,7 @@ typedef struct fasim_scan_stats {
 	int64_t kernel_launches[5];
 	int64_t cells_stage1, cells_stage2, cells_stage3;   /* DP cells actually executed (stage 3: fwd + rev)   */
 	int64_t hazard_units;               /* units re-run by the stripe-faithful kernel (possible Q2)  */
+	int64_t rev_exact;                  /* window tries whose reverse pass ran on the stripe-faithful kernel */
 } fasim_scan_stats;
 
 typedef struct fasim_result {

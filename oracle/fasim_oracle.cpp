@@ -147,6 +147,9 @@ static const int GAPO = 16, GAPE = 4, BIAS = 4;
 
 struct EndInfo { int score, ref, read; };
 
+// test hook: when false the lazy-F exit uses the unsigned comparison (what the reference would compute without Q2)
+static thread_local bool g_signed_lazy_f = true;
+
 static inline uint8_t adds8(uint8_t a, uint8_t b) { int v = a + b; return (uint8_t)(v > 255 ? 255 : v); }
 static inline uint8_t subs8(uint8_t a, uint8_t b) { return (uint8_t)(a > b ? a - b : 0); }
 
@@ -213,7 +216,7 @@ static EndInfo sw_byte(const int8_t* ref, int dir, int refLen, const int8_t* rea
 					hs[s] = h;
 					h = subs8(h, GAPO);
 					vF[s] = subs8(vF[s], GAPE);
-					if ((int8_t)vF[s] > (int8_t)h) any = true;
+					if (g_signed_lazy_f ? ((int8_t)vF[s] > (int8_t)h) : (vF[s] > h)) any = true;
 				}
 				if (!any) goto lazy_done;
 			}
@@ -813,6 +816,14 @@ void parse_dna_header(const std::string& header, std::string& species, std::stri
 } // namespace fo
 
 extern "C" {
+// column maxima with the lazy-F exit made unsigned (no Q2): used by tests to locate units where Q2 matters
+void fo_pre_align_noq2(const char* rna, int m, const char* target, int n, int* out_cols)
+{
+	fo::g_signed_lazy_f = false;
+	std::vector<int> c = fo::pre_align(std::string(rna, m), std::string(target, n));
+	fo::g_signed_lazy_f = true;
+	memcpy(out_cols, c.data(), sizeof(int) * n);
+}
 int fo_stage1_max(const char* rna, int m, const char* target, int n) { return fo::stage1_max(std::string(rna, m), std::string(target, n)); }
 void fo_pre_align(const char* rna, int m, const char* target, int n, int* out_cols)
 {

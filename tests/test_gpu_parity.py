@@ -104,6 +104,40 @@ def test_scan_records_match_reference_fastsim(mod, engine, h19, golden_dir, scan
     assert res.stats["candidates"] == sum(u["ncand"] for u in units)
 
 
+def test_q2_units_scan(mod, engine, h19, golden_dir):
+    """Segments with units where the reference's signed lazy-F exit (Q2) changes results: the hazard detection of the
+    systolic kernels must send them to the stripe-faithful kernels."""
+    hdr, dna = synth.read_fasta(os.path.join(golden_dir, "q2cat.fa"))
+    _, units = helpers.parse_scan(helpers.gunzip(os.path.join(golden_dir, "q2cat.scan.gz")))
+    engine.set_query(h19)
+    res = engine.scan(dna, mod.default_params(cLength=20, overlapLength=0))
+    assert res.stats["candidates"] == sum(u["ncand"] for u in units)
+    assert res.triplexes() == _expected_triplexes(units)
+    assert res.stats["hazard_units"] >= 19
+    p = mod.default_params(cLength=40, overlapLength=0)
+    res = engine.scan(dna, p)
+    _, chro, start = mod.parse_dna_header(hdr)
+    assert mod.tfosorted(res, chro, start, p) == open(os.path.join(golden_dir, "q2cat.TFOsorted"), "rb").read()
+
+
+def test_systolic_and_stripe_faithful_paths_agree(mod, h19, golden_dir, monkeypatch):
+    """FASIM_SCAN_V1 / FASIM_ALIGN_V1 force the stripe-faithful kernels everywhere; records must be identical."""
+    _, dna = synth.read_fasta(os.path.join(golden_dir, "planted40k.fa"))
+    p = mod.default_params(cLength=20)
+    e2 = mod.Engine(0)
+    e2.set_query(h19)
+    fast = e2.scan(dna, p)
+    e2.close()
+    monkeypatch.setenv("FASIM_SCAN_V1", "1")
+    monkeypatch.setenv("FASIM_ALIGN_V1", "1")
+    e1 = mod.Engine(0)
+    e1.set_query(h19)
+    slow = e1.scan(dna, p)
+    e1.close()
+    assert fast.recs == slow.recs and fast.pool == slow.pool
+    assert fast.stats["kernel_launches"][0] > 0 and slow.stats["kernel_launches"][0] == 0
+
+
 @pytest.mark.parametrize("name,dna_name,kw", [
     ("demo_lg40.TFOsorted", "testDNA.fa", dict(cLength=40)),
     ("demo_default.TFOsorted", "testDNA.fa", dict()),

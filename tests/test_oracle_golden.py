@@ -76,3 +76,23 @@ def test_batch_vectors(oracle_build, golden_dir):
             else:
                 assert five == exp and (cig or "*") == g[6], rq[:80]
     assert kinds == {"S", "P", "K", "A"}
+
+
+def test_q2_units_fixture(oracle_build, golden_dir):
+    """19 whole segments, each holding a unit where the signed lazy-F exit (Q2) changes the column maxima."""
+    rna, dna = os.path.join(golden_dir, "H19.fa"), os.path.join(golden_dir, "q2cat.fa")
+    out = helpers.oracle_cli(oracle_build, "scan", rna, dna, "-o", "0", "-detail", "0", "-threads", "8")
+    assert out == helpers.gunzip(os.path.join(golden_dir, "q2cat.scan.gz"))
+    out = helpers.oracle_cli(oracle_build, "tfosorted", rna, dna, "-o", "0", "-lg", "40", "-threads", "8")
+    assert out == open(os.path.join(golden_dir, "q2cat.TFOsorted"), "rb").read()
+    # the fixture really contains Q2 units: the unsigned-exit variant of the oracle gives different columns
+    import ctypes
+    o = helpers.Oracle(oracle_build)
+    o.lib.fo_pre_align_noq2.restype = None
+    o.lib.fo_pre_align_noq2.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    _, q = synth.read_fasta(rna)
+    _, d = synth.read_fasta(dna)
+    t, _ = o.encode_unit(d[:5000], 44)
+    b = (ctypes.c_int * len(t))()
+    o.lib.fo_pre_align_noq2(q, len(q), t, len(t), b)
+    assert o.pre_align(q, t) != list(b)
