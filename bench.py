@@ -106,25 +106,9 @@ def main():
 
     def step():
         res = eng.scan(None, p)
-        if world > 1:
-            # the path's one exchange step: gather the shard's records on rank 0 over RCCL
-            payload = torch.frombuffer(bytearray(res.recs + res.pool) or bytearray(1), dtype=torch.uint8).cuda()
-            sizes = [torch.zeros(2, dtype=torch.int64, device="cuda") for _ in range(world)]
-            dist.all_gather(sizes, torch.tensor([len(res.recs), len(res.pool)], dtype=torch.int64, device="cuda"))
-            mx = max(int(s.sum()) for s in sizes)
-            buf = torch.zeros(max(mx, 1), dtype=torch.uint8, device="cuda")
-            buf[: payload.numel()] = payload
-            gathered = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
-            dist.gather(buf, gathered, dst=0)
-            if rank == 0:
-                parts = []
-                for s, g in zip(sizes, gathered):
-                    nr, npool = int(s[0]), int(s[1])
-                    b = g[: nr + npool].cpu().numpy().tobytes()
-                    parts.append(mod.ScanResult(b[:nr], b[nr:], {}))
-                merged = mod.merge_results(parts)
-                return res, merged.count
-        return res, res.count
+        # the path's one exchange step: gather every rank's records on rank 0 (RCCL over xGMI)
+        merged = mod.gather_results(res, dist, rank, world, "cuda")
+        return res, (merged.count if merged is not None else 0)
 
     def sync():
         torch.cuda.synchronize()

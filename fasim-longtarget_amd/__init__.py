@@ -166,6 +166,40 @@ def merge_results(parts):
     return ScanResult(b"".join(recs), b"".join(pool), {})
 
 
+def shard_segments(nseg: int, rank: int, world: int):
+    """Contiguous block of segment indices for `rank` (blocks differ by at most one segment)."""
+    base, rem = divmod(nseg, world)
+    first = rank * base + min(rank, rem)
+    return first, base + (1 if rank < rem else 0)
+
+
+def gather_results(res: ScanResult, dist, rank: int, world: int, device: str = "cuda"):
+    """The path's only exchange step: every rank contributes the records of its segment shard, rank 0 gets them
+    merged in rank order (= canonical (segment, encoding, rank) order because shards are contiguous).
+    Two collectives: an all_gather of (records bytes, pool bytes) and a gather of the padded payloads.
+    `dist` is torch.distributed (backend nccl = RCCL over xGMI on the GPU box; gloo in the CPU tests)."""
+    import torch
+    if world == 1:
+        return res
+    sizes = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([len(res.recs), len(res.pool)], dtype=torch.int64, device=device))
+    mx = max(1, max(int(s.sum()) for s in sizes))
+    buf = torch.zeros(mx, dtype=torch.uint8, device=device)
+    payload = res.recs + res.pool
+    if payload:
+        buf[: len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(device)
+    gathered = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, gathered, dst=0)
+    if rank != 0:
+        return None
+    parts = []
+    for s, g in zip(sizes, gathered):
+        nr, npool = int(s[0]), int(s[1])
+        b = g[: nr + npool].cpu().numpy().tobytes()
+        parts.append(ScanResult(b[:nr], b[nr:], {}))
+    return merge_results(parts)
+
+
 class Engine:
     """One engine per GPU (one process per GPU in multi-GPU runs)."""
 
