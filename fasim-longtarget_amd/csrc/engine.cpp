@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -47,6 +48,19 @@ struct DevBuf {
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// FASIM_PROFILE=1: wall-clock accumulators of the host phases, printed to stderr at the end of fasim_scan
+struct HostProf {
+	static constexpr int N = 16;
+	double t[N] = { 0 }; const char* name[N] = { nullptr };
+	bool on = false;
+	std::mutex mu;
+	void add(int i, const char* nm, double dt) { if (on) { std::lock_guard<std::mutex> g(mu); t[i] += dt; name[i] = nm; } }
+	void dump() { if (!on) return; for (int i = 0; i < N; i++) if (name[i]) fprintf(stderr, "[fasim prof] %-28s %8.3f s\n", name[i], t[i]); }
+	void reset() { for (int i = 0; i < N; i++) { t[i] = 0; name[i] = nullptr; } }
+};
+HostProf g_prof;
+struct ProfScope { int i; const char* nm; double t0; ProfScope(int i_, const char* n) : i(i_), nm(n), t0(now_s()) {} ~ProfScope() { g_prof.add(i, nm, now_s() - t0); } };
+
 } // namespace
 
 struct fasim_engine {
@@ -60,6 +74,8 @@ struct fasim_engine {
 		stage1, hits, hits_total, hit_off, hit_cnt, thr, ends, bprobs, bout, scratch, colmax16, unit_ids, flags, stage1_in, hits2,
 		fprobs, ftasks, fstream, fout, aout, cigpool, cigcount;
 	bool align_v1 = false;        // FASIM_ALIGN_V1=1: force the stripe-faithful kernels for stage 3
+	std::vector<fasim_engine*> workers;   // extra engines on the same device: batches in flight concurrently
+	int host_threads_total = 1;
 	bool query_acgt = true;       // query holds only A,C,G,T: stage-1 and stage-2 scoring coincide on N-free segments
 	bool scan_v1 = false;         // FASIM_SCAN_V1=1: force the stripe-faithful kernels for stages 1 and 2
 	int host_threads = 1;
@@ -342,6 +358,7 @@ int run_align(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>
 	const int n = (int)W.size();
 	out.assign(n, AlignResult());
 	if (!n) return FASIM_OK;
+	ProfScope ps(6, "run_align (exact) total");
 	std::vector<StripedProb> probs(n);
 	for (int k = 0; k < n; k++) {
 		probs[k].tbase = (int64_t)W[k].unit * B.tstride; probs[k].t0 = W[k].t0; probs[k].ref_len = W[k].len;
@@ -444,6 +461,7 @@ int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& 
 	const int n = (int)W.size();
 	fo.resize(n);
 	if (!n) return FASIM_OK;
+	ProfScope ps(0, "run_fwd total");
 	std::vector<FwdProb> probs(n);
 	int64_t off = 0;
 	for (int k = 0; k < n; k++) {
@@ -455,8 +473,10 @@ int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& 
 	std::vector<int32_t> tasks;
 	for (int k = 0; k < n; k += per_task) tasks.push_back(k);
 	tasks.push_back(n);
+	double tp = now_s();
 	int rc = upload(E, E->fprobs, probs.data(), sizeof(FwdProb) * n); if (rc) return rc;
 	rc = upload(E, E->ftasks, tasks.data(), sizeof(int32_t) * tasks.size()); if (rc) return rc;
+	g_prof.add(1, "run_fwd upload", now_s() - tp);
 	HIPOK(E->fstream.ensure((size_t)off + 256));
 	HIPOK(E->fout.ensure(sizeof(FwdOut) * n));
 	hipError_t he = launch_build_stream(E->tcodes.as<uint8_t>(), E->fprobs.as<FwdProb>(), n, E->fstream.as<uint8_t>(), E->st);
@@ -467,8 +487,13 @@ int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& 
 	L.out = E->fout.as<FwdOut>();
 	{ TimedScope ts(E, 2); he = launch_align_fwd(L, E->st); }
 	if (he != hipSuccess) return fail(E, FASIM_E_HIP, "align_fwd launch failed: %s", hipGetErrorString(he));
+	tp = now_s();
+	HIPOK(hipStreamSynchronize(E->st));
+	g_prof.add(2, "run_fwd kernel wait", now_s() - tp);
+	tp = now_s();
 	HIPOK(hipMemcpyAsync(fo.data(), E->fout.p, sizeof(FwdOut) * n, hipMemcpyDeviceToHost, E->st));
 	HIPOK(hipStreamSynchronize(E->st));
+	g_prof.add(3, "run_fwd D2H", now_s() - tp);
 	return FASIM_OK;
 }
 
@@ -480,6 +505,7 @@ int run_rev_exact(fasim_engine* E, const UnitBatch& B, const std::vector<WindowP
 {
 	const int n = (int)idx.size();
 	if (!n) return FASIM_OK;
+	ProfScope ps(5, "run_rev_exact total");
 	std::vector<StripedProb> probs(n);
 	for (int i = 0; i < n; i++) {
 		const int k = idx[i];
@@ -510,6 +536,7 @@ int run_finish(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb
 	const int n = (int)W.size();
 	out.assign(n, AlignResult()); status.assign(n, 0);
 	if (!n) return FASIM_OK;
+	ProfScope ps(4, "run_finish total");
 	std::vector<FwdProb> probs(n);
 	for (int k = 0; k < n; k++) { probs[k].tbase = (int64_t)W[k].unit * B.tstride + W[k].t0; probs[k].len = W[k].len; probs[k].stream_off = 0; }
 	const int scratch_cap = 8192;
@@ -636,6 +663,7 @@ int fasim_engine_create(int device, fasim_engine** out)
 	unsigned hc = std::thread::hardware_concurrency();
 	const char* env = getenv("FASIM_HOST_THREADS");
 	E->host_threads = env ? std::max(1, atoi(env)) : (int)std::min(32u, std::max(1u, hc));
+	E->host_threads_total = E->host_threads;
 	const char* v1 = getenv("FASIM_SCAN_V1");
 	E->scan_v1 = v1 && atoi(v1) != 0;
 	const char* a1 = getenv("FASIM_ALIGN_V1");
@@ -647,6 +675,8 @@ int fasim_engine_create(int device, fasim_engine** out)
 void fasim_engine_destroy(fasim_engine* e)
 {
 	if (!e) return;
+	for (fasim_engine* w : e->workers) fasim_engine_destroy(w);
+	e->workers.clear();
 	(void)hipSetDevice(e->device);
 	DevBuf* bufs[] = { &e->q1, &e->q2, &e->enc_lut, &e->counter, &e->dna, &e->seg_start, &e->seg_len, &e->enc_ids, &e->tcodes,
 		&e->colmax, &e->probs, &e->max_out, &e->unit_len, &e->stage1, &e->hits, &e->hits_total, &e->hit_off, &e->hit_cnt, &e->thr,
@@ -814,6 +844,250 @@ void fasim_synth_dna(char* out, int64_t n, uint64_t seed)
 }
 
 // ---- the batched body of LongTarget() ---------------------------------------------------------------
+// One batch of segments [b0, b1) on one worker engine (own stream and buffers): encode, scan, candidates, window
+// alignments, triplex records.  Several batches run concurrently on different workers (fasim_scan below).
+int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t* dna_dev, int64_t shard_lo, int64_t b0, int64_t b1,
+	const fasim_params& p, const std::vector<int>& encs, int tstride, std::vector<HostTriplex>& all, fasim_scan_stats& st)
+{
+	int rc = FASIM_OK;
+	const int64_t step = p.cutLength - p.overlapLength;
+	const int nenc = (int)encs.size();
+	{
+		// segments of this batch that are not skipped by same_seq()
+		std::vector<int32_t> sstart, slen; std::vector<int64_t> sidx;
+		for (int64_t s = b0; s < b1; s++) {
+			const int64_t pos = s * step;
+			const int len = (int)std::min<int64_t>(p.cutLength, dna_len - pos);
+			st.segments++;
+			if (same_seq(dna + pos, len)) { st.segments_skipped++; continue; }
+			sstart.push_back((int32_t)(pos - shard_lo)); slen.push_back(len); sidx.push_back(s);
+			st.logical_cells += (int64_t)E->m * len * nenc;
+		}
+		const int nseg = (int)sidx.size();
+		if (!nseg) return FASIM_OK;
+		UnitBatch B; B.nunit = nseg * nenc; B.tstride = tstride; B.unit_len.resize(B.nunit);
+		for (int s = 0; s < nseg; s++) for (int k = 0; k < nenc; k++) B.unit_len[s * nenc + k] = slen[s];
+		st.units += B.nunit;
+		for (int s = 0; s < nseg; s++) { st.cells_stage1 += (int64_t)E->m * slen[s] * nenc; st.cells_stage2 += (int64_t)E->m * slen[s] * nenc; }
+		rc = upload(E, E->seg_start, sstart.data(), sizeof(int32_t) * nseg); if (rc) return rc;
+		rc = upload(E, E->seg_len, slen.data(), sizeof(int32_t) * nseg); if (rc) return rc;
+		rc = upload(E, E->unit_len, B.unit_len.data(), sizeof(int32_t) * B.nunit); if (rc) return rc;
+		HIPOK(E->tcodes.ensure((size_t)B.nunit * tstride));
+		hipError_t he;
+		{ TimedScope ts(E, 4);
+		he = launch_encode(dna_dev, E->seg_start.as<int32_t>(), E->seg_len.as<int32_t>(), nseg,
+			E->enc_ids.as<int32_t>(), nenc, E->enc_lut.as<uint8_t>(), E->tcodes.as<uint8_t>(), tstride, E->st); }
+		if (he != hipSuccess) return fail(E, FASIM_E_HIP, "encode launch failed: %s", hipGetErrorString(he));
+
+		// ---- stages 1+2: fused systolic scan (scan.hip); stripe-faithful kernels for hazard units, for
+		//      queries beyond 3072 rows, or when FASIM_SCAN_V1=1
+		double t0 = now_s();
+		std::vector<int32_t> hoff, hcnt, thr;
+		std::vector<uint32_t> hits;
+		bool done_v2 = false;
+		if (!E->scan_v1) {
+			std::vector<char> need1(B.nunit, E->query_acgt ? 0 : 1);
+			if (E->query_acgt) {
+				for (int s = 0; s < nseg; s++) {
+					const char* sg = dna + sidx[s] * step; bool clean = true;
+					for (int i = 0; i < slen[s]; i++) { const char c = sg[i]; if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T')) { clean = false; break; } }
+					if (!clean) for (int k = 0; k < nenc; k++) need1[s * nenc + k] = 1;
+				}
+			}
+			ScanOut so;
+			rc = run_scan_v2(E, B, need1, so, &st);
+			if (rc < 0) return rc;
+			if (rc == 0) { hoff.swap(so.hit_off); hcnt.swap(so.hit_cnt); thr.swap(so.thr); hits.swap(so.hits); done_v2 = true; }
+		}
+		st.t_stage2_s += now_s() - t0;
+		if (!done_v2) {
+		// ---- stage 1
+		t0 = now_s();
+		std::vector<int> s1;
+		rc = run_stage1(E, B, s1, &st.stage1_word_reruns); if (rc) return rc;
+		st.t_stage1_s += now_s() - t0;
+
+		// ---- stage 2 + hits
+		t0 = now_s();
+		rc = run_stage2(E, B); if (rc) return rc;
+		rc = upload(E, E->stage1, s1.data(), sizeof(int32_t) * B.nunit); if (rc) return rc;
+		HIPOK(E->hit_off.ensure(sizeof(int32_t) * B.nunit)); HIPOK(E->hit_cnt.ensure(sizeof(int32_t) * B.nunit));
+		HIPOK(E->thr.ensure(sizeof(int32_t) * B.nunit)); HIPOK(E->hits_total.ensure(64));
+		hoff.resize(B.nunit); hcnt.resize(B.nunit); thr.resize(B.nunit);
+		std::vector<int32_t> pre_max(B.nunit);
+		size_t hits_cap = std::max<size_t>(E->hits.cap / 4, (size_t)B.nunit * 128);
+		for (;;) {
+			HIPOK(E->hits.ensure(hits_cap * sizeof(uint32_t)));
+			{ TimedScope ts(E, 4);
+			he = launch_hits(E->colmax.as<uint8_t>(), nullptr, E->unit_len.as<int32_t>(), E->stage1.as<int32_t>(), B.nunit, tstride,
+				E->hits.as<uint32_t>(), (uint32_t)hits_cap, E->hits_total.as<uint32_t>(), E->hit_off.as<int32_t>(),
+				E->hit_cnt.as<int32_t>(), E->thr.as<int32_t>(), E->st); }
+			if (he != hipSuccess) return fail(E, FASIM_E_HIP, "hits launch failed: %s", hipGetErrorString(he));
+			uint32_t total = 0;
+			HIPOK(hipMemcpyAsync(&total, E->hits_total.p, sizeof total, hipMemcpyDeviceToHost, E->st));
+			HIPOK(hipStreamSynchronize(E->st));
+			if (total <= hits_cap) { hits.resize(total); break; }
+			hits_cap = (size_t)total + 1024;
+		}
+		HIPOK(hipMemcpyAsync(hoff.data(), E->hit_off.p, sizeof(int32_t) * B.nunit, hipMemcpyDeviceToHost, E->st));
+		HIPOK(hipMemcpyAsync(hcnt.data(), E->hit_cnt.p, sizeof(int32_t) * B.nunit, hipMemcpyDeviceToHost, E->st));
+		HIPOK(hipMemcpyAsync(thr.data(), E->thr.p, sizeof(int32_t) * B.nunit, hipMemcpyDeviceToHost, E->st));
+		HIPOK(hipMemcpyAsync(pre_max.data(), E->max_out.p, sizeof(int32_t) * B.nunit, hipMemcpyDeviceToHost, E->st));
+		if (!hits.empty()) HIPOK(hipMemcpyAsync(hits.data(), E->hits.p, sizeof(uint32_t) * hits.size(), hipMemcpyDeviceToHost, E->st));
+		HIPOK(hipStreamSynchronize(E->st));
+		for (int u = 0; u < B.nunit; u++) if (pre_max[u] == 255) st.stage2_overflow_units++;
+		st.t_stage2_s += now_s() - t0;
+		}
+
+		// ---- candidates (a7) and the window tries (a8).  fastSIM() decides on sw_score and ref_end only
+		//      (fastsim.h:218-235); both are known after the FORWARD pass (the reverse pass returns the same
+		//      score: sswNew.cpp:1518 takes the minimum), so up to four forward rounds run first and the reverse
+		//      pass + traceback (k_finish) run once, for the chosen try.  Candidates with a try that may hit
+		//      the reference's layout-dependent behaviour, or whose traceback fails in the reference (NULL ->
+		//      score 0 -> the loop would have continued), are replayed try by try on the stripe-faithful path.
+		t0 = now_s();
+		struct CandState { int unit; Cand c; AlignResult al, best; FwdOut fsel, fbest; int cut, bestcut; char done, flag, exact; };
+		std::vector<uint32_t> cigars;
+		std::vector<CandState> cs;
+		{
+			ProfScope ps(7, "pick candidates");
+			std::vector<Cand> tmp;
+			for (int u = 0; u < B.nunit; u++) {
+				pick_candidates(hits.data() + hoff[u], hcnt[u], tmp);
+				for (const Cand& c : tmp) { CandState x; memset(&x.fsel, 0, sizeof x.fsel); memset(&x.fbest, 0, sizeof x.fbest);
+					x.unit = u; x.c = c; x.done = 0; x.cut = 0; x.bestcut = 0; x.flag = 0; x.exact = 0; cs.push_back(x); }
+			}
+		}
+		st.candidates += (int64_t)cs.size();
+		bool v2 = true;
+		{ std::vector<WindowProb> probe(1, WindowProb{ 0, 0, 1 }); v2 = align_v2_fits(E, probe); }
+		if (v2) {
+			for (int it = 0; it < 4; it++) {
+				std::vector<WindowProb> W; std::vector<int> who;
+				for (size_t k = 0; k < cs.size(); k++) {
+					if (cs[k].done) continue;
+					int cut;
+					if (!window_for_try(it, cs[k].c.score, cs[k].c.pos, &cut)) { cs[k].done = 1; continue; }
+					cs[k].cut = cut;
+					W.push_back({ cs[k].unit, cs[k].c.pos - cut + 1, cut });
+					who.push_back((int)k);
+				}
+				if (W.empty()) break;
+				st.align_calls += (int64_t)W.size();
+				for (const WindowProb& w : W) st.cells_stage3 += (int64_t)E->m * w.len;
+				std::vector<FwdOut> fo;
+				rc = run_fwd(E, B, W, fo); if (rc) return rc;
+				{
+					// score >= 148: the REVERSE pass (its own stripe geometry) could hit Q2 -> exact reverse pass now,
+					// so that sw_score = min(forward, reverse) is known before the decision
+					std::vector<int> rv;
+					for (size_t i = 0; i < fo.size(); i++) if (!fo[i].flags && fo[i].score >= 148 && fo[i].score < 255 - BIAS) rv.push_back((int)i);
+					rc = run_rev_exact(E, B, W, fo, rv); if (rc) return rc;
+					st.rev_exact += (int64_t)rv.size();
+				}
+				for (size_t i = 0; i < who.size(); i++) {
+					CandState& x = cs[who[i]];
+					const FwdOut& f = fo[i];
+					// flag 1: the forward pass may hit Q2 (or the exact reverse pass was unusable); scores >= 251 go through
+					// the reference's 16-bit kernels: both are replayed on the stripe-faithful path
+					if ((f.flags & 1) || (!(f.flags & 2) && f.score >= 148)) { x.exact = 1; x.done = 1; continue; }
+					x.fsel = f;                                                                        // "last tried" so far
+					if (f.score >= x.c.score) { x.flag = 1; x.done = 1; continue; }                    // fastsim.h:218-221
+					if (f.score > x.fbest.score && f.ref_end == x.cut - 1) { x.fbest = f; x.bestcut = x.cut; x.flag = 2; }   // :222-235
+				}
+			}
+			// the chosen try of every candidate -> reverse pass + traceback
+			std::vector<WindowProb> W; std::vector<FwdOut> fsel; std::vector<int> who;
+			for (size_t k = 0; k < cs.size(); k++) {
+				CandState& x = cs[k];
+				if (x.exact) continue;
+				if (x.flag == 2) { x.fsel = x.fbest; x.cut = x.bestcut; }                              // fastsim.h:238-250
+				if (x.fsel.score <= 0) { x.al.sw_score = 0; continue; }
+				W.push_back({ x.unit, x.c.pos - x.cut + 1, x.cut }); fsel.push_back(x.fsel); who.push_back((int)k);
+			}
+			std::vector<AlignResult> res; std::vector<char> status;
+			rc = run_finish(E, B, W, fsel, res, cigars, status); if (rc) return rc;
+			for (size_t i = 0; i < who.size(); i++) {
+				CandState& x = cs[who[i]];
+				if (status[i] != 0) { x.exact = 1; continue; }
+				x.al = res[i];
+				st.cells_stage3 += (int64_t)(x.al.ref_end - x.al.ref_begin + 1) * (x.al.query_end - x.al.query_begin + 1);
+			}
+		}
+		// stripe-faithful replay (all candidates when the systolic kernels do not fit the query)
+		{
+			std::vector<int> ex;
+			for (size_t k = 0; k < cs.size(); k++) if (!v2 || cs[k].exact) { ex.push_back((int)k); cs[k].done = 0; cs[k].flag = 0; cs[k].best = AlignResult(); cs[k].al = AlignResult(); }
+			if (v2) st.align_word_reruns += (int64_t)ex.size();
+			for (int it = 0; it < 4 && !ex.empty(); it++) {
+				std::vector<WindowProb> W; std::vector<int> who;
+				for (int k : ex) {
+					if (cs[k].done) continue;
+					int cut;
+					if (!window_for_try(it, cs[k].c.score, cs[k].c.pos, &cut)) { cs[k].done = 1; continue; }
+					cs[k].cut = cut;
+					W.push_back({ cs[k].unit, cs[k].c.pos - cut + 1, cut });
+					who.push_back(k);
+				}
+				if (W.empty()) break;
+				if (!v2) { st.align_calls += (int64_t)W.size(); for (const WindowProb& w : W) st.cells_stage3 += (int64_t)E->m * w.len; }
+				std::vector<AlignResult> res;
+				rc = run_align(E, B, W, res, cigars, nullptr); if (rc) return rc;
+				for (size_t i = 0; i < who.size(); i++) {
+					CandState& x = cs[who[i]];
+					x.al = res[i];
+					if (x.al.sw_score >= x.c.score) { x.flag = 1; x.done = 1; continue; }
+					if (x.al.sw_score > x.best.sw_score && x.al.ref_end == x.cut - 1) { x.best = x.al; x.bestcut = x.cut; x.flag = 2; }
+				}
+			}
+			for (int k : ex) if (cs[k].flag == 2) { cs[k].al = cs[k].best; cs[k].cut = cs[k].bestcut; }
+		}
+		st.t_stage3_s += now_s() - t0;
+
+		// ---- host: triplex records per unit (a12-a14), then LongTarget()'s tail filter (a15)
+		t0 = now_s();
+		std::vector<std::vector<HostTriplex>> per_unit(B.nunit);
+		std::vector<char> seg_acgtn(nseg);
+		for (int s = 0; s < nseg; s++) seg_acgtn[s] = only_acgtn(dna + sidx[s] * step, slen[s]) ? 1 : 0;
+		{
+			std::vector<size_t> first(B.nunit + 1, 0);
+			for (const CandState& x : cs) first[x.unit + 1]++;
+			for (int u = 0; u < B.nunit; u++) first[u + 1] += first[u];
+			std::atomic<int> next(0);
+			auto work = [&]() {
+				for (;;) {
+					const int u = next.fetch_add(1);
+					if (u >= B.nunit) break;
+					if (first[u] == first[u + 1]) continue;
+					const int s = u / nenc, enc = encs[u % nenc];
+					const char* seg = dna + sidx[s] * step;
+					const long dna_start = (long)(sidx[s] * step);
+					std::vector<HostTriplex> mine;
+					const bool acgtn = seg_acgtn[s] != 0;
+					for (size_t k = first[u]; k < first[u + 1]; k++) {
+						CandState& x = cs[k];
+						AlignResult al = x.al; const int cut = x.cut;
+						if (al.sw_score == 0) continue;                                                    // fastsim.h:253
+						al.ref_begin += x.c.pos - cut + 1; al.ref_end += x.c.pos - cut + 1;                // :254-255
+						convert_triplex(al, cigars.data() + al.cigar_off, E->rna, seg, slen[s], enc, dna_start, p, mine, acgtn);
+					}
+					dedup_top(mine, p, per_unit[u]);
+					for (HostTriplex& t : per_unit[u]) { t.seg = (int)sidx[s]; t.enc = enc; }
+				}
+			};
+			const int nt = std::max(1, std::min(E->host_threads, B.nunit));
+			if (nt == 1) work();
+			else { std::vector<std::thread> th; for (int k = 0; k < nt; k++) th.emplace_back(work); for (auto& t : th) t.join(); }
+		}
+		for (int u = 0; u < B.nunit; u++)
+			for (HostTriplex& t : per_unit[u])
+				if (t.score >= p.scoreMin && t.identity >= p.minIdentity && t.tri_score >= p.minStability && t.nt >= p.cLength)   // Fasim-LongTarget.cpp:589-597
+					all.push_back(std::move(t));
+		st.t_host_s += now_s() - t0;
+	}
+	return FASIM_OK;
+}
+
 int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_first, int64_t seg_count,
 	const fasim_params* pp, fasim_result** out)
 {
@@ -830,8 +1104,7 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 	HIPOK(hipSetDevice(E->device));
 	const double t_begin = now_s();
 	fasim_scan_stats st; memset(&st, 0, sizeof st);
-	drain_timed(E);
-	for (int k = 0; k < 5; k++) { E->kernel_ms[k] = 0; E->kernel_launches[k] = 0; }
+	{ const char* pe = getenv("FASIM_PROFILE"); g_prof.on = pe && atoi(pe) != 0; g_prof.reset(); }
 
 	const int64_t nseg_all = fasim_segment_count(dna_len, &p);
 	if (seg_first < 0) seg_first = 0;
@@ -848,248 +1121,64 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 		const uint8_t* dna_dev;
 		if (resident) dna_dev = E->dna_res.as<uint8_t>() + shard_lo;
 		else { rc = upload(E, E->dna, dna + shard_lo, (size_t)(shard_hi - shard_lo)); if (rc) return rc; dna_dev = E->dna.as<uint8_t>(); }
-		rc = upload(E, E->enc_ids, encs.data(), sizeof(int) * nenc); if (rc) return rc;
-
 		const int tstride = (p.cutLength + 15) & ~15;
-		// batch size: bounded by memory for tcodes+colmax and by the stage-3 record volume
-		// ~2048 segments x 48 encodings per batch: amortises launch/transfer overheads and the latency floor of the
-		// stripe-faithful re-runs (one 16-lane group per hazard unit); bounded by memory (4 B per target column)
-		int64_t seg_batch = std::max<int64_t>(1, std::min<int64_t>(2048, ((int64_t)24 << 30) / ((int64_t)4 * nenc * tstride)));
+		// Batches of ~512 segments x 48 encodings; several batches are in flight at once on worker engines (own HIP
+		// stream + buffers + host thread), so the latency-bound kernels (stripe-faithful re-runs, tracebacks) and the
+		// host-side work of one batch overlap the VALU-bound kernels of another.
+		int64_t seg_batch = std::max<int64_t>(1, std::min<int64_t>(512, ((int64_t)8 << 30) / ((int64_t)4 * nenc * tstride)));
 		const char* envb = getenv("FASIM_SEG_BATCH");
 		if (envb) seg_batch = std::max(1, atoi(envb));
-
-		for (int64_t b0 = seg_first; b0 < seg_first + seg_count; b0 += seg_batch) {
-			const int64_t b1 = std::min(seg_first + seg_count, b0 + seg_batch);
-			// segments of this batch that are not skipped by same_seq()
-			std::vector<int32_t> sstart, slen; std::vector<int64_t> sidx;
-			for (int64_t s = b0; s < b1; s++) {
-				const int64_t pos = s * step;
-				const int len = (int)std::min<int64_t>(p.cutLength, dna_len - pos);
-				st.segments++;
-				if (same_seq(dna + pos, len)) { st.segments_skipped++; continue; }
-				sstart.push_back((int32_t)(pos - shard_lo)); slen.push_back(len); sidx.push_back(s);
-				st.logical_cells += (int64_t)E->m * len * nenc;
-			}
-			const int nseg = (int)sidx.size();
-			if (!nseg) continue;
-			UnitBatch B; B.nunit = nseg * nenc; B.tstride = tstride; B.unit_len.resize(B.nunit);
-			for (int s = 0; s < nseg; s++) for (int k = 0; k < nenc; k++) B.unit_len[s * nenc + k] = slen[s];
-			st.units += B.nunit;
-			for (int s = 0; s < nseg; s++) { st.cells_stage1 += (int64_t)E->m * slen[s] * nenc; st.cells_stage2 += (int64_t)E->m * slen[s] * nenc; }
-			rc = upload(E, E->seg_start, sstart.data(), sizeof(int32_t) * nseg); if (rc) return rc;
-			rc = upload(E, E->seg_len, slen.data(), sizeof(int32_t) * nseg); if (rc) return rc;
-			rc = upload(E, E->unit_len, B.unit_len.data(), sizeof(int32_t) * B.nunit); if (rc) return rc;
-			HIPOK(E->tcodes.ensure((size_t)B.nunit * tstride));
-			hipError_t he;
-			{ TimedScope ts(E, 4);
-			he = launch_encode(dna_dev, E->seg_start.as<int32_t>(), E->seg_len.as<int32_t>(), nseg,
-				E->enc_ids.as<int32_t>(), nenc, E->enc_lut.as<uint8_t>(), E->tcodes.as<uint8_t>(), tstride, E->st); }
-			if (he != hipSuccess) return fail(E, FASIM_E_HIP, "encode launch failed: %s", hipGetErrorString(he));
-
-			// ---- stages 1+2: fused systolic scan (scan.hip); stripe-faithful kernels for hazard units, for
-			//      queries beyond 3072 rows, or when FASIM_SCAN_V1=1
-			double t0 = now_s();
-			std::vector<int32_t> hoff, hcnt, thr;
-			std::vector<uint32_t> hits;
-			bool done_v2 = false;
-			if (!E->scan_v1) {
-				std::vector<char> need1(B.nunit, E->query_acgt ? 0 : 1);
-				if (E->query_acgt) {
-					for (int s = 0; s < nseg; s++) {
-						const char* sg = dna + sidx[s] * step; bool clean = true;
-						for (int i = 0; i < slen[s]; i++) { const char c = sg[i]; if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T')) { clean = false; break; } }
-						if (!clean) for (int k = 0; k < nenc; k++) need1[s * nenc + k] = 1;
-					}
-				}
-				ScanOut so;
-				rc = run_scan_v2(E, B, need1, so, &st);
-				if (rc < 0) return rc;
-				if (rc == 0) { hoff.swap(so.hit_off); hcnt.swap(so.hit_cnt); thr.swap(so.thr); hits.swap(so.hits); done_v2 = true; }
-			}
-			st.t_stage2_s += now_s() - t0;
-			if (!done_v2) {
-			// ---- stage 1
-			t0 = now_s();
-			std::vector<int> s1;
-			rc = run_stage1(E, B, s1, &st.stage1_word_reruns); if (rc) return rc;
-			st.t_stage1_s += now_s() - t0;
-
-			// ---- stage 2 + hits
-			t0 = now_s();
-			rc = run_stage2(E, B); if (rc) return rc;
-			rc = upload(E, E->stage1, s1.data(), sizeof(int32_t) * B.nunit); if (rc) return rc;
-			HIPOK(E->hit_off.ensure(sizeof(int32_t) * B.nunit)); HIPOK(E->hit_cnt.ensure(sizeof(int32_t) * B.nunit));
-			HIPOK(E->thr.ensure(sizeof(int32_t) * B.nunit)); HIPOK(E->hits_total.ensure(64));
-			hoff.resize(B.nunit); hcnt.resize(B.nunit); thr.resize(B.nunit);
-			std::vector<int32_t> pre_max(B.nunit);
-			size_t hits_cap = std::max<size_t>(E->hits.cap / 4, (size_t)B.nunit * 128);
+		std::vector<std::pair<int64_t, int64_t>> chunks;
+		for (int64_t b0 = seg_first; b0 < seg_first + seg_count; b0 += seg_batch) chunks.push_back({ b0, std::min(seg_first + seg_count, b0 + seg_batch) });
+		int nworkers = 6;
+		const char* envw = getenv("FASIM_WORKERS");
+		if (envw) nworkers = std::max(1, std::min(8, atoi(envw)));
+		nworkers = (int)std::min<size_t>((size_t)nworkers, chunks.size());
+		// worker 0 is this engine; the others are lazily created engines on the same device sharing the query
+		while ((int)E->workers.size() < nworkers - 1) {
+			fasim_engine* w = nullptr;
+			rc = fasim_engine_create(E->device, &w); if (rc) return fail(E, rc, "cannot create worker engine: %s", fasim_last_error(nullptr));
+			E->workers.push_back(w);
+		}
+		std::vector<fasim_engine*> ws(1, E);
+		for (int k = 0; k < nworkers - 1; k++) ws.push_back(E->workers[k]);
+		for (fasim_engine* w : ws) {
+			if (w != E && (w->rna != E->rna)) { rc = fasim_set_query(w, E->rna.data(), E->m); if (rc) return fail(E, rc, "worker set_query failed: %s", fasim_last_error(w)); }
+			w->scan_v1 = E->scan_v1; w->align_v1 = E->align_v1;
+			w->host_threads = std::max(1, E->host_threads_total / nworkers);
+			HIPOK(hipSetDevice(E->device));
+			rc = upload(w, w->enc_ids, encs.data(), sizeof(int) * nenc); if (rc) return rc;
+			drain_timed(w);
+			for (int k = 0; k < 5; k++) { w->kernel_ms[k] = 0; w->kernel_launches[k] = 0; }
+		}
+		std::vector<std::vector<HostTriplex>> per_chunk(chunks.size());
+		std::vector<fasim_scan_stats> wst(ws.size());
+		for (auto& x : wst) memset(&x, 0, sizeof x);
+		std::vector<int> wrc(ws.size(), FASIM_OK);
+		std::atomic<size_t> next(0);
+		auto run = [&](size_t wi) {
+			(void)hipSetDevice(E->device);
 			for (;;) {
-				HIPOK(E->hits.ensure(hits_cap * sizeof(uint32_t)));
-				{ TimedScope ts(E, 4);
-				he = launch_hits(E->colmax.as<uint8_t>(), nullptr, E->unit_len.as<int32_t>(), E->stage1.as<int32_t>(), B.nunit, tstride,
-					E->hits.as<uint32_t>(), (uint32_t)hits_cap, E->hits_total.as<uint32_t>(), E->hit_off.as<int32_t>(),
-					E->hit_cnt.as<int32_t>(), E->thr.as<int32_t>(), E->st); }
-				if (he != hipSuccess) return fail(E, FASIM_E_HIP, "hits launch failed: %s", hipGetErrorString(he));
-				uint32_t total = 0;
-				HIPOK(hipMemcpyAsync(&total, E->hits_total.p, sizeof total, hipMemcpyDeviceToHost, E->st));
-				HIPOK(hipStreamSynchronize(E->st));
-				if (total <= hits_cap) { hits.resize(total); break; }
-				hits_cap = (size_t)total + 1024;
+				const size_t c = next.fetch_add(1);
+				if (c >= chunks.size()) break;
+				const int r = scan_batch(ws[wi], dna, dna_len, dna_dev, shard_lo, chunks[c].first, chunks[c].second, p, encs, tstride, per_chunk[c], wst[wi]);
+				if (r) { wrc[wi] = r; break; }
 			}
-			HIPOK(hipMemcpyAsync(hoff.data(), E->hit_off.p, sizeof(int32_t) * B.nunit, hipMemcpyDeviceToHost, E->st));
-			HIPOK(hipMemcpyAsync(hcnt.data(), E->hit_cnt.p, sizeof(int32_t) * B.nunit, hipMemcpyDeviceToHost, E->st));
-			HIPOK(hipMemcpyAsync(thr.data(), E->thr.p, sizeof(int32_t) * B.nunit, hipMemcpyDeviceToHost, E->st));
-			HIPOK(hipMemcpyAsync(pre_max.data(), E->max_out.p, sizeof(int32_t) * B.nunit, hipMemcpyDeviceToHost, E->st));
-			if (!hits.empty()) HIPOK(hipMemcpyAsync(hits.data(), E->hits.p, sizeof(uint32_t) * hits.size(), hipMemcpyDeviceToHost, E->st));
-			HIPOK(hipStreamSynchronize(E->st));
-			for (int u = 0; u < B.nunit; u++) if (pre_max[u] == 255) st.stage2_overflow_units++;
-			st.t_stage2_s += now_s() - t0;
-			}
-
-			// ---- candidates (a7) and the window tries (a8).  fastSIM() decides on sw_score and ref_end only
-			//      (fastsim.h:218-235); both are known after the FORWARD pass (the reverse pass returns the same
-			//      score: sswNew.cpp:1518 takes the minimum), so up to four forward rounds run first and the reverse
-			//      pass + traceback (k_finish) run once, for the chosen try.  Candidates with a try that may hit
-			//      the reference's layout-dependent behaviour, or whose traceback fails in the reference (NULL ->
-			//      score 0 -> the loop would have continued), are replayed try by try on the stripe-faithful path.
-			t0 = now_s();
-			struct CandState { int unit; Cand c; AlignResult al, best; FwdOut fsel, fbest; int cut, bestcut; char done, flag, exact; };
-			std::vector<uint32_t> cigars;
-			std::vector<CandState> cs;
-			{
-				std::vector<Cand> tmp;
-				for (int u = 0; u < B.nunit; u++) {
-					pick_candidates(hits.data() + hoff[u], hcnt[u], tmp);
-					for (const Cand& c : tmp) { CandState x; memset(&x.fsel, 0, sizeof x.fsel); memset(&x.fbest, 0, sizeof x.fbest);
-						x.unit = u; x.c = c; x.done = 0; x.cut = 0; x.bestcut = 0; x.flag = 0; x.exact = 0; cs.push_back(x); }
-				}
-			}
-			st.candidates += (int64_t)cs.size();
-			bool v2 = true;
-			{ std::vector<WindowProb> probe(1, WindowProb{ 0, 0, 1 }); v2 = align_v2_fits(E, probe); }
-			if (v2) {
-				for (int it = 0; it < 4; it++) {
-					std::vector<WindowProb> W; std::vector<int> who;
-					for (size_t k = 0; k < cs.size(); k++) {
-						if (cs[k].done) continue;
-						int cut;
-						if (!window_for_try(it, cs[k].c.score, cs[k].c.pos, &cut)) { cs[k].done = 1; continue; }
-						cs[k].cut = cut;
-						W.push_back({ cs[k].unit, cs[k].c.pos - cut + 1, cut });
-						who.push_back((int)k);
-					}
-					if (W.empty()) break;
-					st.align_calls += (int64_t)W.size();
-					for (const WindowProb& w : W) st.cells_stage3 += (int64_t)E->m * w.len;
-					std::vector<FwdOut> fo;
-					rc = run_fwd(E, B, W, fo); if (rc) return rc;
-					{
-						// score >= 148: the REVERSE pass (its own stripe geometry) could hit Q2 -> exact reverse pass now,
-						// so that sw_score = min(forward, reverse) is known before the decision
-						std::vector<int> rv;
-						for (size_t i = 0; i < fo.size(); i++) if (!fo[i].flags && fo[i].score >= 148 && fo[i].score < 255 - BIAS) rv.push_back((int)i);
-						rc = run_rev_exact(E, B, W, fo, rv); if (rc) return rc;
-						st.rev_exact += (int64_t)rv.size();
-					}
-					for (size_t i = 0; i < who.size(); i++) {
-						CandState& x = cs[who[i]];
-						const FwdOut& f = fo[i];
-						// flag 1: the forward pass may hit Q2 (or the exact reverse pass was unusable); scores >= 251 go through
-						// the reference's 16-bit kernels: both are replayed on the stripe-faithful path
-						if ((f.flags & 1) || (!(f.flags & 2) && f.score >= 148)) { x.exact = 1; x.done = 1; continue; }
-						x.fsel = f;                                                                        // "last tried" so far
-						if (f.score >= x.c.score) { x.flag = 1; x.done = 1; continue; }                    // fastsim.h:218-221
-						if (f.score > x.fbest.score && f.ref_end == x.cut - 1) { x.fbest = f; x.bestcut = x.cut; x.flag = 2; }   // :222-235
-					}
-				}
-				// the chosen try of every candidate -> reverse pass + traceback
-				std::vector<WindowProb> W; std::vector<FwdOut> fsel; std::vector<int> who;
-				for (size_t k = 0; k < cs.size(); k++) {
-					CandState& x = cs[k];
-					if (x.exact) continue;
-					if (x.flag == 2) { x.fsel = x.fbest; x.cut = x.bestcut; }                              // fastsim.h:238-250
-					if (x.fsel.score <= 0) { x.al.sw_score = 0; continue; }
-					W.push_back({ x.unit, x.c.pos - x.cut + 1, x.cut }); fsel.push_back(x.fsel); who.push_back((int)k);
-				}
-				std::vector<AlignResult> res; std::vector<char> status;
-				rc = run_finish(E, B, W, fsel, res, cigars, status); if (rc) return rc;
-				for (size_t i = 0; i < who.size(); i++) {
-					CandState& x = cs[who[i]];
-					if (status[i] != 0) { x.exact = 1; continue; }
-					x.al = res[i];
-					st.cells_stage3 += (int64_t)(x.al.ref_end - x.al.ref_begin + 1) * (x.al.query_end - x.al.query_begin + 1);
-				}
-			}
-			// stripe-faithful replay (all candidates when the systolic kernels do not fit the query)
-			{
-				std::vector<int> ex;
-				for (size_t k = 0; k < cs.size(); k++) if (!v2 || cs[k].exact) { ex.push_back((int)k); cs[k].done = 0; cs[k].flag = 0; cs[k].best = AlignResult(); cs[k].al = AlignResult(); }
-				if (v2) st.align_word_reruns += (int64_t)ex.size();
-				for (int it = 0; it < 4 && !ex.empty(); it++) {
-					std::vector<WindowProb> W; std::vector<int> who;
-					for (int k : ex) {
-						if (cs[k].done) continue;
-						int cut;
-						if (!window_for_try(it, cs[k].c.score, cs[k].c.pos, &cut)) { cs[k].done = 1; continue; }
-						cs[k].cut = cut;
-						W.push_back({ cs[k].unit, cs[k].c.pos - cut + 1, cut });
-						who.push_back(k);
-					}
-					if (W.empty()) break;
-					if (!v2) { st.align_calls += (int64_t)W.size(); for (const WindowProb& w : W) st.cells_stage3 += (int64_t)E->m * w.len; }
-					std::vector<AlignResult> res;
-					rc = run_align(E, B, W, res, cigars, nullptr); if (rc) return rc;
-					for (size_t i = 0; i < who.size(); i++) {
-						CandState& x = cs[who[i]];
-						x.al = res[i];
-						if (x.al.sw_score >= x.c.score) { x.flag = 1; x.done = 1; continue; }
-						if (x.al.sw_score > x.best.sw_score && x.al.ref_end == x.cut - 1) { x.best = x.al; x.bestcut = x.cut; x.flag = 2; }
-					}
-				}
-				for (int k : ex) if (cs[k].flag == 2) { cs[k].al = cs[k].best; cs[k].cut = cs[k].bestcut; }
-			}
-			st.t_stage3_s += now_s() - t0;
-
-			// ---- host: triplex records per unit (a12-a14), then LongTarget()'s tail filter (a15)
-			t0 = now_s();
-			std::vector<std::vector<HostTriplex>> per_unit(B.nunit);
-			std::vector<char> seg_acgtn(nseg);
-			for (int s = 0; s < nseg; s++) seg_acgtn[s] = only_acgtn(dna + sidx[s] * step, slen[s]) ? 1 : 0;
-			{
-				std::vector<size_t> first(B.nunit + 1, 0);
-				for (const CandState& x : cs) first[x.unit + 1]++;
-				for (int u = 0; u < B.nunit; u++) first[u + 1] += first[u];
-				std::atomic<int> next(0);
-				auto work = [&]() {
-					for (;;) {
-						const int u = next.fetch_add(1);
-						if (u >= B.nunit) break;
-						if (first[u] == first[u + 1]) continue;
-						const int s = u / nenc, enc = encs[u % nenc];
-						const char* seg = dna + sidx[s] * step;
-						const long dna_start = (long)(sidx[s] * step);
-						std::vector<HostTriplex> mine;
-						const bool acgtn = seg_acgtn[s] != 0;
-						for (size_t k = first[u]; k < first[u + 1]; k++) {
-							CandState& x = cs[k];
-							AlignResult al = x.al; const int cut = x.cut;
-							if (al.sw_score == 0) continue;                                                    // fastsim.h:253
-							al.ref_begin += x.c.pos - cut + 1; al.ref_end += x.c.pos - cut + 1;                // :254-255
-							convert_triplex(al, cigars.data() + al.cigar_off, E->rna, seg, slen[s], enc, dna_start, p, mine, acgtn);
-						}
-						dedup_top(mine, p, per_unit[u]);
-						for (HostTriplex& t : per_unit[u]) { t.seg = (int)sidx[s]; t.enc = enc; }
-					}
-				};
-				const int nt = std::max(1, std::min(E->host_threads, B.nunit));
-				if (nt == 1) work();
-				else { std::vector<std::thread> th; for (int k = 0; k < nt; k++) th.emplace_back(work); for (auto& t : th) t.join(); }
-			}
-			for (int u = 0; u < B.nunit; u++)
-				for (HostTriplex& t : per_unit[u])
-					if (t.score >= p.scoreMin && t.identity >= p.minIdentity && t.tri_score >= p.minStability && t.nt >= p.cLength)   // Fasim-LongTarget.cpp:589-597
-						all.push_back(std::move(t));
-			st.t_host_s += now_s() - t0;
+			(void)hipStreamSynchronize(ws[wi]->st);
+		};
+		if (ws.size() == 1) run(0);
+		else { std::vector<std::thread> th; for (size_t wi = 0; wi < ws.size(); wi++) th.emplace_back(run, wi); for (auto& t : th) t.join(); }
+		for (size_t wi = 0; wi < ws.size(); wi++) if (wrc[wi]) { if (ws[wi] != E) E->err = ws[wi]->err; return wrc[wi]; }
+		for (auto& v : per_chunk) for (HostTriplex& t : v) all.push_back(std::move(t));
+		for (size_t wi = 0; wi < ws.size(); wi++) {
+			const fasim_scan_stats& x = wst[wi];
+			st.segments += x.segments; st.segments_skipped += x.segments_skipped; st.units += x.units; st.candidates += x.candidates;
+			st.align_calls += x.align_calls; st.align_word_reruns += x.align_word_reruns; st.stage2_overflow_units += x.stage2_overflow_units;
+			st.stage1_word_reruns += x.stage1_word_reruns; st.logical_cells += x.logical_cells; st.t_stage1_s += x.t_stage1_s;
+			st.t_stage2_s += x.t_stage2_s; st.t_stage3_s += x.t_stage3_s; st.t_host_s += x.t_host_s; st.cells_stage1 += x.cells_stage1;
+			st.cells_stage2 += x.cells_stage2; st.cells_stage3 += x.cells_stage3; st.hazard_units += x.hazard_units; st.rev_exact += x.rev_exact;
+			drain_timed(ws[wi]);
+			for (int k = 0; k < 5; k++) { st.kernel_ms[k] += ws[wi]->kernel_ms[k]; st.kernel_launches[k] += ws[wi]->kernel_launches[k]; }
 		}
 	}
 
@@ -1112,10 +1201,11 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 		r.tfo_off = (int64_t)off; memcpy(R->pool + off, t.tfo.c_str(), t.tfo.size() + 1); off += t.tfo.size() + 1;
 		r.tts_off = (int64_t)off; memcpy(R->pool + off, t.tts.c_str(), t.tts.size() + 1); off += t.tts.size() + 1;
 	}
-	(void)hipStreamSynchronize(E->st);
-	drain_timed(E);
-	for (int k = 0; k < 5; k++) { st.kernel_ms[k] = E->kernel_ms[k]; st.kernel_launches[k] = E->kernel_launches[k]; }
 	st.t_total_s = now_s() - t_begin;
+	if (g_prof.on) {
+		fprintf(stderr, "[fasim prof] total %.3f s  stage2 %.3f  stage3 %.3f  host %.3f\n", st.t_total_s, st.t_stage2_s, st.t_stage3_s, st.t_host_s);
+		g_prof.dump();
+	}
 	R->stats = st;
 	*out = R;
 	return FASIM_OK;
