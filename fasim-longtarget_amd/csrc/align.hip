@@ -85,7 +85,7 @@ struct FwdArgs {
 };
 
 template <int RP>
-__global__ void __launch_bounds__(256) k_align_fwd(FwdArgs a)
+__global__ void __launch_bounds__(512) k_align_fwd(FwdArgs a)
 {
 	__shared__ __align__(16) uint8_t prof[6 * AL_CODE_STRIDE];
 	const int lane = threadIdx.x & 63;
@@ -264,9 +264,10 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st)
 {
 	hipError_t err = hipMemsetAsync(a.counter, 0, sizeof(uint32_t), st);
 	if (err != hipSuccess) return err;
-	long blocks = ((long)a.ntask + 3) / 4;
-	if (blocks > 256 * 3) blocks = 256 * 3;
-	hipLaunchKernelGGL(k_align_fwd<RP>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+	// 8 waves share one 43 KB profile: 2 workgroups per CU = 4 waves per SIMD (the VGPR limit)
+	long blocks = ((long)a.ntask + 7) / 8;
+	if (blocks > 256 * 2) blocks = 256 * 2;
+	hipLaunchKernelGGL(k_align_fwd<RP>, dim3((unsigned)blocks), dim3(512), 0, st, a);
 	return hipGetLastError();
 }
 
@@ -350,10 +351,11 @@ __device__ int reverse_pass(const uint8_t* __restrict__ tw /* window codes */, c
 __global__ void __launch_bounds__(64) k_finish(const uint8_t* __restrict__ tcodes, const uint8_t* __restrict__ qcodes,
 	const FwdProb* __restrict__ probs, const FwdOut* __restrict__ fwd, int32_t nprob, uint8_t* __restrict__ scratch,
 	int32_t scratch_cap, AlignOutDev* __restrict__ out, uint32_t* __restrict__ cigar_pool, uint32_t pool_cap,
-	uint32_t* __restrict__ pool_count)
+	uint32_t* __restrict__ pool_count, const int32_t* __restrict__ idx_list)
 {
-	const int pi = blockIdx.x * blockDim.x + threadIdx.x;
-	if (pi >= nprob) return;
+	const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+	if (gid >= nprob) return;
+	const int pi = idx_list ? idx_list[gid] : gid;          // scratch slot = gid, result slot = pi
 	const FwdProb pb = probs[pi];
 	const FwdOut fo = fwd[pi];
 	AlignOutDev* o = out + pi;
@@ -361,7 +363,7 @@ __global__ void __launch_bounds__(64) k_finish(const uint8_t* __restrict__ tcode
 	o->cigar_off = 0;
 	if (fo.flags & 1) { o->status = 10; return; }                  // possible Q2 in the forward pass: stripe-faithful re-run
 	if (fo.score <= 0 || fo.ref_end < 0) { o->status = 0; return; }   // nothing aligned
-	uint8_t* my = scratch + (int64_t)pi * scratch_cap;
+	uint8_t* my = scratch + (int64_t)gid * scratch_cap;
 	const uint8_t* tw = tcodes + pb.tbase;
 	int ref_begin = fo.ref_begin, read_begin = fo.read_begin;
 	if (!(fo.flags & 2)) {
@@ -469,15 +471,211 @@ __global__ void __launch_bounds__(64) k_finish(const uint8_t* __restrict__ tcode
 	o->cigar_len = l;
 }
 
-hipError_t launch_finish(const uint8_t* tcodes, const uint8_t* qcodes, const FwdProb* probs, const FwdOut* fwd, int32_t nprob,
-	uint8_t* scratch, int32_t scratch_cap, AlignOutDev* out, uint32_t* cigar_pool, uint32_t pool_cap, uint32_t* pool_count,
-	hipStream_t st)
+
+// ------------------------------------------------------------------------------------------------
+// k_finish_lds: the same reverse pass + banded_sw with the small per-alignment arrays in LDS (256 B per thread,
+// word-interleaved across the 64 threads so equal indices fall into different banks: 16 KB per workgroup, ~10 waves
+// per CU) and the direction matrix (1 byte per cell, [cell][lane] inside a per-wave slab) in global memory: its writes
+// are fire-and-forget and only the traceback reads it back.  Alignments that do not fit report status 2 and are
+// finished by k_finish.
+//   words  0..63 : reverse pass ring, entry (row & 63): lo16 = G, hi16 = E   (reused by the banded arrays afterwards)
+//   words  0..31 : banded: h_b (lo16) / e_b (hi16)
+//   words 32..63 : banded: h_c (lo16)
+// ------------------------------------------------------------------------------------------------
+constexpr int FL_WORDS = 64;
+constexpr int FL_RING = 64;
+constexpr int FL_W = 32;              // max band array width (2*band+3)
+constexpr int FL_CELLS = 2048;        // direction cells per alignment
+
+struct LdsArena {
+	uint32_t* base;                   // &lds[threadIdx.x]; word k lives at base[k * 64]
+	__device__ __forceinline__ int lo(int k) const { return (int)(int16_t)(base[k * 64] & 0xffffu); }
+	__device__ __forceinline__ int hi(int k) const { return (int)(int16_t)(base[k * 64] >> 16); }
+	__device__ __forceinline__ void set(int k, int l, int h) const { base[k * 64] = ((uint32_t)(uint16_t)(int16_t)l) | ((uint32_t)(uint16_t)(int16_t)h << 16); }
+	__device__ __forceinline__ void set_lo(int k, int l) const { base[k * 64] = (base[k * 64] & 0xffff0000u) | (uint32_t)(uint16_t)(int16_t)l; }
+	__device__ __forceinline__ void set_hi(int k, int h) const { base[k * 64] = (base[k * 64] & 0x0000ffffu) | ((uint32_t)(uint16_t)(int16_t)h << 16); }
+};
+
+constexpr int GL_NEG = -30000;        // int16-safe "minus infinity" of the reverse pass
+
+__device__ int reverse_pass_lds(const uint8_t* __restrict__ tw, const uint8_t* __restrict__ q, int S, int ref_end, int read_end,
+	const LdsArena& A, int* ref_begin, int* read_begin)
 {
+	const int R = read_end + 1, C = ref_end + 1;
+	const int g0 = swsc(q[read_end], tw[ref_end]);
+	if (g0 <= 0) return 1;
+	if (g0 == S) { *ref_begin = ref_end; *read_begin = read_end; return 0; }
+	int lo = 0, hi = 0;
+	A.set(0, g0, GL_NEG);
+	// (a vertical gap straight out of the corner cell scores 5 - 16 < 0: column 0 holds row 0 only)
+	for (int j = 1; j < C; j++) {
+		const int tcode = tw[ref_end - j];
+		int F = GL_NEG, diag = GL_NEG, nlo = -1, nhi = -1;
+		const int colrest = C - 1 - j;
+		if (hi - lo + 2 >= FL_RING) return 2;             // band wider than the ring: finish in global memory
+		for (int i = lo; i < R; i++) {
+			const bool in = (i <= hi);
+			const int k = i & (FL_RING - 1);
+			const int gp = in ? A.lo(k) : GL_NEG;
+			const int ep = in ? A.hi(k) : GL_NEG;
+			int e = max(ep - GAP_EXT, gp - GAP_OPEN);
+			int g = diag > GL_NEG / 2 ? diag + swsc(q[read_end - i], tcode) : GL_NEG;
+			g = max(g, max(e, F));
+			const int rest = min(R - 1 - i, colrest);
+			if (g <= 0 || g + 5 * rest < S) g = GL_NEG;
+			if (e <= 0 || e + 5 * rest < S) e = GL_NEG;
+			if (g == S) { *ref_begin = ref_end - j; *read_begin = read_end - i; return 0; }
+			diag = gp;
+			A.set(k, g, e);
+			if (g > GL_NEG / 2 || e > GL_NEG / 2) { if (nlo < 0) nlo = i; nhi = i; }
+			F = max(F - GAP_EXT, g - GAP_OPEN);
+			if (F <= 0) F = GL_NEG;
+			if (i > hi && F <= GL_NEG / 2 && diag <= GL_NEG / 2) break;
+			if (i - lo + 2 >= FL_RING) return 2;
+		}
+		if (nlo < 0) return 1;
+		lo = nlo; hi = nhi;
+	}
+	return 1;
+}
+
+__global__ void __launch_bounds__(64) k_finish_lds(const uint8_t* __restrict__ tcodes, const uint8_t* __restrict__ qcodes,
+	const FwdProb* __restrict__ probs, const FwdOut* __restrict__ fwd, const int32_t* __restrict__ order, int32_t nprob,
+	uint8_t* __restrict__ dirs, AlignOutDev* __restrict__ out, uint32_t* __restrict__ cigar_pool, uint32_t pool_cap,
+	uint32_t* __restrict__ pool_count)
+{
+	__shared__ uint32_t lds[FL_WORDS * 64];
+	const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+	if (gid >= nprob) return;
+	const int pi = order ? order[gid] : gid;              // alignments are processed in an order that groups similar sizes
+	LdsArena A; A.base = lds + threadIdx.x;
+	uint8_t* dir = dirs + (int64_t)blockIdx.x * (64 * FL_CELLS) + threadIdx.x;    // cell c at dir[c * 64]
+	const FwdProb pb = probs[pi];
+	const FwdOut fo = fwd[pi];
+	AlignOutDev* o = out + pi;
+	o->sw_score = 0; o->ref_begin = 0; o->ref_end = fo.ref_end; o->query_begin = 0; o->query_end = fo.read_end; o->cigar_len = 0;
+	o->cigar_off = 0;
+	if (fo.flags & 1) { o->status = 10; return; }
+	if (fo.score <= 0 || fo.ref_end < 0) { o->status = 0; return; }
+	const uint8_t* tw = tcodes + pb.tbase;
+	int ref_begin = fo.ref_begin, read_begin = fo.read_begin;
+	if (!(fo.flags & 2)) {
+		if (fo.score >= 148) { o->status = 11; return; }
+		const int r = reverse_pass_lds(tw, qcodes, fo.score, fo.ref_end, fo.read_end, A, &ref_begin, &read_begin);
+		if (r) { o->status = r == 2 ? 2 : 11; return; }
+	}
+	o->ref_begin = ref_begin; o->query_begin = read_begin;
+	const uint8_t* ref = tw + ref_begin;
+	const uint8_t* read = qcodes + read_begin;
+	const int refLen = fo.ref_end - ref_begin + 1, readLen = fo.read_end - read_begin + 1, score = fo.score;
+	int band = (refLen > readLen ? refLen - readLen : readLen - refLen) + 1;
+	int maxv = 0, width = 0, width_d = 0;
+	do {
+		width = band * 2 + 3; width_d = band * 2 + 1;
+		if (width + 1 > FL_W || width_d * readLen > FL_CELLS) { o->status = 2; return; }
+		for (int j = 1; j < width - 1; j++) A.set_lo(j, 0);                 // h_b[j] = 0
+		for (int i = 0; i < readLen; i++) {
+			int beg = 0, end = refLen - 1, u = 0;
+			if (i - band > beg) beg = i - band;
+			if (i + band < end) end = i + band;
+			const int edge = end + 1 < width - 1 ? end + 1 : width - 1;
+			int f = 0;
+			A.set(0, 0, 0); A.set(edge, 0, 0); A.set_lo(32, 0);               // h_b[0]=e_b[0]=h_b[edge]=e_b[edge]=h_c[0]=0
+			const int x = i - band > 0 ? i - band : 0;
+			const int xp = i - 1 - band > 0 ? i - 1 - band : 0;
+			const int rd = read[i];
+			const int rowcell = width_d * i;
+			for (int j = beg; j <= end; j++) {
+				u = j - x + 1;
+				const int e = j - xp + 1, b = j - x, d = j - xp;
+				int t1 = i == 0 ? -GAP_OPEN : A.lo(e) - GAP_OPEN;
+				int t2 = i == 0 ? -GAP_EXT : A.hi(e) - GAP_EXT;
+				const int ev = t1 > t2 ? t1 : t2;
+				const int de = t1 > t2 ? 1 : 0;
+				t1 = A.lo(32 + b) - GAP_OPEN;
+				t2 = f - GAP_EXT;
+				f = t1 > t2 ? t1 : t2;
+				const int df = t1 > t2 ? 1 : 0;
+				const int e1 = ev > 0 ? ev : 0;
+				const int f1 = f > 0 ? f : 0;
+				t1 = e1 > f1 ? e1 : f1;
+				t2 = A.lo(d) + swsc(ref[j], rd);                                  // h_b[d] (still the previous row's)
+				const int hv = t1 > t2 ? t1 : t2;
+				A.set_hi(u, ev);                                                  // e_b[u]
+				A.set_lo(32 + u, hv);                                             // h_c[u]
+				if (hv > maxv) maxv = hv;
+				const int dh = (t1 <= t2) ? 0 : (e1 > f1 ? 1 : 2);
+				// bit0: E opened (3) vs extended (2); bit1: F opened (5) vs extended (4); bits 2-3: H from diag / E / F
+				dir[(int64_t)(rowcell + (j - x)) * 64] = (uint8_t)(de | (df << 1) | (dh << 2));
+			}
+			for (int j = 1; j <= u; j++) A.set_lo(j, A.lo(32 + j));               // h_b[j] = h_c[j]
+		}
+		band *= 2;
+		if (maxv < score && band > 4 * (refLen + readLen) + 16) { o->status = 3; return; }
+	} while (maxv < score);
+	band /= 2;
+	uint32_t rc[ALIGN_MAX_CIGAR];
+	int l = 0;
+	int i = readLen - 1, j = refLen - 1, e = 0, state = 2, op = 0, prev_op = 0, status = 0;
+	while (i > 0) {
+		const int x = i - band > 0 ? i - band : 0;
+		int beg = 0, end = refLen - 1;
+		if (i - band > beg) beg = i - band;
+		if (i + band < end) end = i + band;
+		if (j < beg || j > end) { status = 3; break; }
+		const uint32_t nib = dir[(int64_t)(width_d * i + (j - x)) * 64];
+		// direction byte of the reference: state 0 (E) -> 3/2, state 1 (F) -> 5/4, state 2 (H) -> 1 or the E/F byte
+		int dv;
+		const int dE = (nib & 1) ? 3 : 2, dF = (nib & 2) ? 5 : 4;
+		if (state == 0) dv = dE; else if (state == 1) dv = dF; else { const int dh = (nib >> 2) & 3; dv = dh == 0 ? 1 : (dh == 1 ? dE : dF); }
+		if (dv == 1) { --i; --j; state = 2; op = 0; }
+		else if (dv == 2) { --i; state = 0; op = 1; }
+		else if (dv == 3) { --i; state = 2; op = 1; }
+		else if (dv == 4) { --j; state = 1; op = 2; }
+		else { --j; state = 2; op = 2; }
+		if (op == prev_op) ++e;
+		else {
+			if (l >= ALIGN_MAX_CIGAR) { status = 4; break; }
+			rc[l++] = cig(e, prev_op);
+			prev_op = op; e = 1;
+		}
+	}
+	if (status == 0) {
+		if (op == 0) { if (l >= ALIGN_MAX_CIGAR) status = 4; else rc[l++] = cig(e + 1, 0); }
+		else { if (l + 2 > ALIGN_MAX_CIGAR) status = 4; else { rc[l++] = cig(e, op); rc[l++] = cig(1, 0); } }
+	}
+	if (status == 0) {
+		const uint32_t off = atomicAdd(pool_count, (uint32_t)l);
+		if ((uint64_t)off + (uint64_t)l > (uint64_t)pool_cap) status = 4;
+		else { o->cigar_off = off; for (int k = 0; k < l; k++) cigar_pool[off + k] = rc[l - 1 - k]; }
+	}
+	o->status = status;
+	if (status != 0) return;
+	o->sw_score = score;
+	o->cigar_len = l;
+}
+
+hipError_t launch_finish(const uint8_t* tcodes, const uint8_t* qcodes, const FwdProb* probs, const FwdOut* fwd, const int32_t* order,
+	int32_t nprob, uint8_t* dirs, AlignOutDev* out, uint32_t* cigar_pool, uint32_t pool_cap, uint32_t* pool_count, hipStream_t st)
+{
+	// LDS-resident kernel for every alignment; the few that do not fit come back with status 2 (see launch_finish_big).
+	// `dirs` must hold ceil(nprob/64) * 64 * 2048 bytes.
 	if (nprob <= 0) return hipSuccess;
 	hipError_t err = hipMemsetAsync(pool_count, 0, sizeof(uint32_t), st);
 	if (err != hipSuccess) return err;
-	hipLaunchKernelGGL(k_finish, dim3((nprob + 63) / 64), dim3(64), 0, st, tcodes, qcodes, probs, fwd, nprob, scratch, scratch_cap, out,
+	hipLaunchKernelGGL(k_finish_lds, dim3((nprob + 63) / 64), dim3(64), 0, st, tcodes, qcodes, probs, fwd, order, nprob, dirs, out,
 		cigar_pool, pool_cap, pool_count);
+	return hipGetLastError();
+}
+
+// global-scratch variant for the listed alignments (results go to out[idx_list[k]], cigars are appended to the same pool)
+hipError_t launch_finish_big(const uint8_t* tcodes, const uint8_t* qcodes, const FwdProb* probs, const FwdOut* fwd,
+	const int32_t* idx_list, int32_t nlist, uint8_t* scratch, int32_t scratch_cap, AlignOutDev* out, uint32_t* cigar_pool,
+	uint32_t pool_cap, uint32_t* pool_count, hipStream_t st)
+{
+	if (nlist <= 0) return hipSuccess;
+	hipLaunchKernelGGL(k_finish, dim3((nlist + 63) / 64), dim3(64), 0, st, tcodes, qcodes, probs, fwd, nlist, scratch, scratch_cap, out,
+		cigar_pool, pool_cap, pool_count, idx_list);
 	return hipGetLastError();
 }
 

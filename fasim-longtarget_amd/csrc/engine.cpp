@@ -72,7 +72,7 @@ struct fasim_engine {
 	ScoreLut lut1, lut2;
 	DevBuf q1, q2, enc_lut, counter, dna, seg_start, seg_len, enc_ids, tcodes, colmax, probs, max_out, unit_len,
 		stage1, hits, hits_total, hit_off, hit_cnt, thr, ends, bprobs, bout, scratch, colmax16, unit_ids, flags, stage1_in, hits2,
-		fprobs, ftasks, fstream, fout, aout, cigpool, cigcount;
+		fprobs, ftasks, fstream, fout, aout, cigpool, cigcount, forder, scratch2;
 	bool align_v1 = false;        // FASIM_ALIGN_V1=1: force the stripe-faithful kernels for stage 3
 	std::vector<fasim_engine*> workers;   // extra engines on the same device: batches in flight concurrently
 	int host_threads_total = 1;
@@ -539,23 +539,50 @@ int run_finish(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb
 	ProfScope ps(4, "run_finish total");
 	std::vector<FwdProb> probs(n);
 	for (int k = 0; k < n; k++) { probs[k].tbase = (int64_t)W[k].unit * B.tstride + W[k].t0; probs[k].len = W[k].len; probs[k].stream_off = 0; }
-	const int scratch_cap = 8192;
+	const int scratch_cap = 16384;
 	int rc = upload(E, E->fprobs, probs.data(), sizeof(FwdProb) * n); if (rc) return rc;
 	rc = upload(E, E->fout, fo.data(), sizeof(FwdOut) * n); if (rc) return rc;
 	HIPOK(E->aout.ensure(sizeof(AlignOutDev) * n));
-	HIPOK(E->scratch.ensure((size_t)n * scratch_cap));
 	const size_t pool_cap = (size_t)n * 12 + 4096;
 	HIPOK(E->cigpool.ensure(pool_cap * sizeof(uint32_t)));
 	HIPOK(E->cigcount.ensure(64));
 	hipError_t he;
+	{
+		// process alignments grouped by score (a proxy for their size): the 64 threads of a wave then run DPs of similar
+		// length instead of all waiting for the largest one
+		std::vector<int32_t> order(n);
+		std::vector<int32_t> cnt(1026, 0);
+		for (int k = 0; k < n; k++) cnt[std::min(1024, std::max(0, fo[k].score)) + 1]++;
+		for (int b = 1; b < 1026; b++) cnt[b] += cnt[b - 1];
+		for (int k = 0; k < n; k++) order[cnt[std::min(1024, std::max(0, fo[k].score))]++] = k;
+		rc = upload(E, E->forder, order.data(), sizeof(int32_t) * n); if (rc) return rc;
+	}
+	HIPOK(E->scratch.ensure((size_t)((n + 63) / 64) * 64 * 2048));
 	{ TimedScope ts(E, 3);
-	he = launch_finish(E->tcodes.as<uint8_t>(), E->q2.as<uint8_t>(), E->fprobs.as<FwdProb>(), E->fout.as<FwdOut>(), n,
-		E->scratch.as<uint8_t>(), scratch_cap, E->aout.as<AlignOutDev>(), E->cigpool.as<uint32_t>(), (uint32_t)pool_cap,
+	he = launch_finish(E->tcodes.as<uint8_t>(), E->q2.as<uint8_t>(), E->fprobs.as<FwdProb>(), E->fout.as<FwdOut>(),
+		E->forder.as<int32_t>(), n, E->scratch.as<uint8_t>(), E->aout.as<AlignOutDev>(), E->cigpool.as<uint32_t>(), (uint32_t)pool_cap,
 		E->cigcount.as<uint32_t>(), E->st); }
 	if (he != hipSuccess) return fail(E, FASIM_E_HIP, "finish launch failed: %s", hipGetErrorString(he));
 	std::vector<AlignOutDev> ao(n);
 	uint32_t pool_used = 0;
 	HIPOK(hipMemcpyAsync(ao.data(), E->aout.p, sizeof(AlignOutDev) * n, hipMemcpyDeviceToHost, E->st));
+	HIPOK(hipStreamSynchronize(E->st));
+	{
+		// alignments whose band / direction matrix did not fit the LDS kernel: same algorithm on global scratch
+		std::vector<int32_t> big;
+		for (int k = 0; k < n; k++) if (ao[k].status == 2) big.push_back(k);
+		if (!big.empty()) {
+			rc = upload(E, E->unit_ids, big.data(), sizeof(int32_t) * big.size()); if (rc) return rc;
+			HIPOK(E->scratch2.ensure(big.size() * (size_t)scratch_cap));
+			{ TimedScope ts(E, 3);
+			he = launch_finish_big(E->tcodes.as<uint8_t>(), E->q2.as<uint8_t>(), E->fprobs.as<FwdProb>(), E->fout.as<FwdOut>(),
+				E->unit_ids.as<int32_t>(), (int)big.size(), E->scratch2.as<uint8_t>(), scratch_cap, E->aout.as<AlignOutDev>(),
+				E->cigpool.as<uint32_t>(), (uint32_t)pool_cap, E->cigcount.as<uint32_t>(), E->st); }
+			if (he != hipSuccess) return fail(E, FASIM_E_HIP, "finish (global scratch) launch failed: %s", hipGetErrorString(he));
+			HIPOK(hipMemcpyAsync(ao.data(), E->aout.p, sizeof(AlignOutDev) * n, hipMemcpyDeviceToHost, E->st));
+			HIPOK(hipStreamSynchronize(E->st));
+		}
+	}
 	HIPOK(hipMemcpyAsync(&pool_used, E->cigcount.p, sizeof pool_used, hipMemcpyDeviceToHost, E->st));
 	HIPOK(hipStreamSynchronize(E->st));
 	if (pool_used > pool_cap) pool_used = (uint32_t)pool_cap;
@@ -681,7 +708,7 @@ void fasim_engine_destroy(fasim_engine* e)
 	DevBuf* bufs[] = { &e->q1, &e->q2, &e->enc_lut, &e->counter, &e->dna, &e->seg_start, &e->seg_len, &e->enc_ids, &e->tcodes,
 		&e->colmax, &e->probs, &e->max_out, &e->unit_len, &e->stage1, &e->hits, &e->hits_total, &e->hit_off, &e->hit_cnt, &e->thr,
 		&e->ends, &e->bprobs, &e->bout, &e->scratch, &e->dna_res, &e->colmax16, &e->unit_ids, &e->flags, &e->stage1_in, &e->hits2,
-		&e->fprobs, &e->ftasks, &e->fstream, &e->fout, &e->aout, &e->cigpool, &e->cigcount };
+		&e->fprobs, &e->ftasks, &e->fstream, &e->fout, &e->aout, &e->cigpool, &e->cigcount, &e->forder, &e->scratch2 };
 	for (auto& t : e->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
 	for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
 	for (DevBuf* b : bufs) b->release();

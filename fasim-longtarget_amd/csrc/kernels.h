@@ -57,8 +57,11 @@ struct FwdLaunch {
 };
 hipError_t launch_build_stream(const uint8_t* tcodes, const FwdProb* probs, int32_t nprob, uint8_t* stream, hipStream_t st);
 hipError_t launch_align_fwd(const FwdLaunch& L, hipStream_t st);     // hipErrorInvalidValue: query too long
-hipError_t launch_finish(const uint8_t* tcodes, const uint8_t* qcodes, const FwdProb* probs, const FwdOut* fwd, int32_t nprob,
-	uint8_t* scratch, int32_t scratch_cap, AlignOutDev* out, uint32_t* cigar_pool, uint32_t pool_cap, uint32_t* pool_count,
-	hipStream_t st);
+hipError_t launch_finish(const uint8_t* tcodes, const uint8_t* qcodes, const FwdProb* probs, const FwdOut* fwd, const int32_t* order,
+	int32_t nprob, uint8_t* dirs, AlignOutDev* out, uint32_t* cigar_pool, uint32_t pool_cap, uint32_t* pool_count, hipStream_t st);
+
+hipError_t launch_finish_big(const uint8_t* tcodes, const uint8_t* qcodes, const FwdProb* probs, const FwdOut* fwd,
+	const int32_t* idx_list, int32_t nlist, uint8_t* scratch, int32_t scratch_cap, AlignOutDev* out, uint32_t* cigar_pool,
+	uint32_t pool_cap, uint32_t* pool_count, hipStream_t st);
 
 } // namespace fasim
