@@ -351,6 +351,9 @@ int run_scan_v2(fasim_engine* E, const UnitBatch& B, const std::vector<char>& un
 
 struct WindowProb { int unit, t0, len; };
 
+int run_finish(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, const std::vector<FwdOut>& fo,
+	std::vector<AlignResult>& out, std::vector<uint32_t>& cigars, std::vector<char>& status);
+
 // a9-a11: ssw_align for a list of windows (forward + reverse on the GPU, 16-bit re-runs, banded traceback)
 int run_align(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, std::vector<AlignResult>& out,
 	std::vector<uint32_t>& cigars, fasim_scan_stats* stats)
@@ -402,6 +405,28 @@ int run_align(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>
 	std::vector<BandOut> bo(bp.size());
 	std::vector<int> todo(bp.size());
 	for (size_t i = 0; i < todo.size(); i++) todo[i] = (int)i;
+	std::vector<char> via_finish(bp.size(), 0);
+	std::vector<AlignResult> fres;
+	if (!E->align_v1 && !bp.empty()) {
+		// traceback through the finish kernel with the exact (ref_begin, read_begin, score) supplied (flag 2); only what
+		// it cannot hold falls through to k_banded below
+		std::vector<WindowProb> W2(bp.size()); std::vector<FwdOut> f2(bp.size());
+		for (size_t i = 0; i < bp.size(); i++) {
+			const int k = bidx[i]; const AlignEnds& e = ends[k];
+			W2[i] = W[k];
+			f2[i].score = bp[i].score; f2[i].ref_end = e.ref_end; f2[i].read_end = e.read_end; f2[i].flags = 2;
+			f2[i].ref_begin = e.ref_begin; f2[i].read_begin = e.read_begin;
+		}
+		std::vector<char> fst;
+		rc = run_finish(E, B, W2, f2, fres, cigars, fst); if (rc) return rc;
+		std::vector<int> left;
+		for (size_t i = 0; i < bp.size(); i++) {
+			if (fst[i] == 2) { left.push_back((int)i); continue; }
+			via_finish[i] = 1;
+			bo[i].status = fst[i] == 0 ? 0 : 1;
+		}
+		todo.swap(left);
+	}
 	size_t cap = 8192;
 	for (int attempt = 0; attempt < 4 && !todo.empty(); attempt++, cap *= 32) {
 		std::vector<BandProb> cur(todo.size());
@@ -439,6 +464,7 @@ int run_align(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>
 		if (bo[i].status != 0) { r.sw_score = 0; continue; }    // NULL from ssw_align -> sw_score 0 (ssw_cpp.cpp:631-633)
 		r.sw_score = bp[i].score; r.ref_begin = e.ref_begin; r.ref_end = e.ref_end;
 		r.query_begin = e.read_begin; r.query_end = e.read_end;
+		if (via_finish[i]) { r.cigar_len = fres[i].cigar_len; r.cigar_off = fres[i].cigar_off; if (fres[i].sw_score <= 0) r.sw_score = 0; continue; }
 		r.cigar_len = bo[i].cigar_len;
 		r.cigar_off = (uint32_t)cigars.size();
 		cigars.insert(cigars.end(), bo[i].cigar, bo[i].cigar + bo[i].cigar_len);
