@@ -33,8 +33,9 @@ import synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_TOPS = 78.6           # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, one 32-bit integer op per lane per clock
-KERNEL_NAMES = ["k_scan (fused stage 1+2)", "k_striped (stage 1/2 hazard re-runs)", "stage-3 alignment kernels",
-                "traceback kernels", "k_encode + hit extraction"]
+KERNEL_NAMES = ["k_scan (fused stage 1+2)", "k_striped<PRE|MAX1> (stage 1/2 hazard re-runs)", "k_align_fwd (stage 3 forward)",
+                "k_finish_lds (reverse pass + traceback)", "k_encode/k_scan_post/k_hits/k_build_stream",
+                "k_striped<ALIGN|REV> (stage 3 exact replays)", "k_finish/k_banded (global scratch)", "-"]
 
 
 def cpu_baseline(rna_path, m, sample_nt, seed):
@@ -78,6 +79,8 @@ def main():
     ap.add_argument("--dna-mb", type=float, default=50.0, help="million nt of synthetic DNA per rank (default 50)")
     ap.add_argument("--cpu-sample-nt", type=int, default=250000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses device 0 (needs --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -89,10 +92,16 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    if args.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
+    xdev = "cuda" if args.backend == "nccl" else "cpu"      # where the exchanged record bytes live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
 
     mod = entry.load()
     eng = mod.Engine(local)
@@ -107,7 +116,7 @@ def main():
     def step():
         res = eng.scan(None, p)
         # the path's one exchange step: gather every rank's records on rank 0 (RCCL over xGMI)
-        merged = mod.gather_results(res, dist, rank, world, "cuda")
+        merged = mod.gather_results(res, dist, rank, world, xdev)
         return res, (merged.count if merged is not None else 0)
 
     def sync():
@@ -135,8 +144,8 @@ def main():
                     agg[k] += v
     sync()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    cells = torch.tensor([float(agg["logical_cells"])], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device=xdev)
+    cells = torch.tensor([float(agg["logical_cells"])], dtype=torch.float64, device=xdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(cells, op=dist.ReduceOp.SUM)
@@ -148,20 +157,20 @@ def main():
         units_per_step = agg["units"] / args.steps
         # dominant kernel by HIP-event time
         kms = agg["kernel_ms"]
-        dom = max(range(5), key=lambda i: kms[i])
+        dom = max(range(8), key=lambda i: kms[i])
         launches = max(1, agg["kernel_launches"][dom])
         avg_ms = kms[dom] / launches
         n_avg = agg["cells_stage2"] / max(1, agg["units"]) / m        # mean segment length
-        if dom == 0:
-            bytes_per_unit, units_dom = n_avg + 5 * m + 4, agg["units"] + agg["stage1_word_reruns"]
-            cells_dom = agg["cells_stage1"]
-        elif dom == 1:
-            bytes_per_unit, units_dom = 3 * n_avg + 5 * m, agg["units"]
-            cells_dom = agg["cells_stage2"]
-        else:
+        if dom == 0:      # k_scan: segment codes (n) + u16 column maxima (2n) + int8-equivalent profile (5m) per unit
+            bytes_per_unit, units_dom = 3 * n_avg + 5 * m, agg["units"] + agg["stage1_word_reruns"]
+            cells_dom, ops_per_cell = agg["cells_stage2"], 5.5
+        elif dom == 1:    # stripe-faithful re-runs of hazard units: n codes + n u8 maxima + profile
+            bytes_per_unit, units_dom = 2 * n_avg + 5 * m, max(1, agg["hazard_units"])
+            cells_dom, ops_per_cell = agg["cells_stage2"] * agg["hazard_units"] / max(1, agg["units"]), 15
+        else:             # window alignments: L codes + profile + 24-byte result per try
             calls = max(1, agg["align_calls"])
             bytes_per_unit, units_dom = agg["cells_stage3"] / m / calls + 5 * m + 24, calls
-            cells_dom = agg["cells_stage3"]
+            cells_dom, ops_per_cell = agg["cells_stage3"], 6
         alg_bytes_per_launch = bytes_per_unit * units_dom / launches
         achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9
         out = {
@@ -183,7 +192,8 @@ def main():
             "mbp_per_s": round(n * world * args.steps / tmax / 1e6, 3),
             "executed_gcells_per_s": round((agg["cells_stage1"] + agg["cells_stage2"] + agg["cells_stage3"]) / (tmax) / 1e9 * 1.0, 3),
             "phase_wall_s": {k: round(agg[k], 3) for k in ("t_stage1_s", "t_stage2_s", "t_stage3_s", "t_host_s", "t_total_s")},
-            "kernel_ms": {KERNEL_NAMES[i]: round(kms[i], 2) for i in range(5)},
+            "kernel_ms": {KERNEL_NAMES[i]: round(kms[i], 2) for i in range(7)},
+            "kernel_launches": {KERNEL_NAMES[i]: int(agg["kernel_launches"][i]) for i in range(7)},
             "counts": {k: int(agg[k]) for k in ("segments", "units", "candidates", "align_calls", "hazard_units", "rev_exact",
                                                 "align_word_reruns", "stage2_overflow_units")},
             "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
@@ -192,9 +202,13 @@ def main():
                          "algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
                          "note": "integer DP is VALU-bound by construction; see valu"},
             "valu": {"kernel": KERNEL_NAMES[dom], "gcells_per_s": round(cells_dom / (kms[dom] * 1e-3) / 1e9, 2),
-                     "ops_per_cell": 15, "achieved_tops": round(cells_dom * 15 / (kms[dom] * 1e-3) / 1e12, 3),
+                     "ops_per_cell": ops_per_cell, "achieved_tops": round(cells_dom * ops_per_cell / (kms[dom] * 1e-3) / 1e12, 3),
                      "peak_tops": VALU_PEAK_TOPS,
-                     "frac": round(cells_dom * 15 / (kms[dom] * 1e-3) / 1e12 / VALU_PEAK_TOPS, 4)},
+                     "frac": round(cells_dom * ops_per_cell / (kms[dom] * 1e-3) / 1e12 / VALU_PEAK_TOPS, 4),
+                     "note": "VALU instructions per DP cell x executed cells / HIP-event time of this kernel family; "
+                             "peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (one VALU instruction per lane per clock; the "
+                             "packed 16-bit kernels process two cells per lane-instruction); kernel times include "
+                             "sharing the GPU with the other batches in flight"},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(rna_path, m, args.cpu_sample_nt, 12345)

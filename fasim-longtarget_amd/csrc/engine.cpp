@@ -86,8 +86,8 @@ struct fasim_engine {
 	struct Timed { hipEvent_t a, b; int family; };
 	std::vector<Timed> timed;
 	std::vector<hipEvent_t> ev_pool;
-	double kernel_ms[5] = { 0, 0, 0, 0, 0 };
-	int64_t kernel_launches[5] = { 0, 0, 0, 0, 0 };
+	double kernel_ms[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	int64_t kernel_launches[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 };
 
 namespace {
@@ -191,7 +191,7 @@ int run_striped(fasim_engine* E, StripedMode mode, bool word, const std::vector<
 	L.colmax = E->colmax.as<uint8_t>(); L.max_out = E->max_out.as<int32_t>(); L.ends = E->ends.as<AlignEnds>();
 	hipError_t he;
 	{
-		TimedScope ts(E, mode == MODE_ALIGN ? 2 : 1);
+		TimedScope ts(E, mode == MODE_ALIGN || mode == MODE_REV ? 5 : 1);
 		he = launch_striped(mode, word, !stage1, L, E->st);
 	}
 	if (he == hipErrorInvalidValue) return fail(E, FASIM_E_UNSUPPORTED, "query of %d nt does not fit the LDS-resident striped kernel", max_qlen);
@@ -442,7 +442,7 @@ int run_align(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>
 			if (rc) return rc;
 			hipError_t he;
 			{
-				TimedScope ts(E, 3);
+				TimedScope ts(E, 6);
 				he = launch_banded(E->tcodes.as<uint8_t>(), E->q2.as<uint8_t>(), E->bprobs.as<BandProb>(), (int)cnt,
 					E->scratch.as<uint8_t>(), E->bout.as<BandOut>(), E->st);
 			}
@@ -600,7 +600,7 @@ int run_finish(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb
 		if (!big.empty()) {
 			rc = upload(E, E->unit_ids, big.data(), sizeof(int32_t) * big.size()); if (rc) return rc;
 			HIPOK(E->scratch2.ensure(big.size() * (size_t)scratch_cap));
-			{ TimedScope ts(E, 3);
+			{ TimedScope ts(E, 6);
 			he = launch_finish_big(E->tcodes.as<uint8_t>(), E->q2.as<uint8_t>(), E->fprobs.as<FwdProb>(), E->fout.as<FwdOut>(),
 				E->unit_ids.as<int32_t>(), (int)big.size(), E->scratch2.as<uint8_t>(), scratch_cap, E->aout.as<AlignOutDev>(),
 				E->cigpool.as<uint32_t>(), (uint32_t)pool_cap, E->cigcount.as<uint32_t>(), E->st); }
@@ -1202,7 +1202,7 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 			HIPOK(hipSetDevice(E->device));
 			rc = upload(w, w->enc_ids, encs.data(), sizeof(int) * nenc); if (rc) return rc;
 			drain_timed(w);
-			for (int k = 0; k < 5; k++) { w->kernel_ms[k] = 0; w->kernel_launches[k] = 0; }
+			for (int k = 0; k < 8; k++) { w->kernel_ms[k] = 0; w->kernel_launches[k] = 0; }
 		}
 		std::vector<std::vector<HostTriplex>> per_chunk(chunks.size());
 		std::vector<fasim_scan_stats> wst(ws.size());
@@ -1231,7 +1231,7 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 			st.t_stage2_s += x.t_stage2_s; st.t_stage3_s += x.t_stage3_s; st.t_host_s += x.t_host_s; st.cells_stage1 += x.cells_stage1;
 			st.cells_stage2 += x.cells_stage2; st.cells_stage3 += x.cells_stage3; st.hazard_units += x.hazard_units; st.rev_exact += x.rev_exact;
 			drain_timed(ws[wi]);
-			for (int k = 0; k < 5; k++) { st.kernel_ms[k] += ws[wi]->kernel_ms[k]; st.kernel_launches[k] += ws[wi]->kernel_launches[k]; }
+			for (int k = 0; k < 8; k++) { st.kernel_ms[k] += ws[wi]->kernel_ms[k]; st.kernel_launches[k] += ws[wi]->kernel_launches[k]; }
 		}
 	}
 

@@ -99,11 +99,12 @@ typedef struct fasim_scan_stats {
 	int64_t stage2_overflow_units, stage1_word_reruns;
 	int64_t logical_cells;              /* m * sum(len(segment)) * n_enc                  */
 	double  t_total_s, t_stage1_s, t_stage2_s, t_stage3_s, t_host_s;   /* host wall clock per phase       */
-	/* HIP-event time of the kernels, summed over launches on the engine's stream.  index: 0 k_scan (fused
-	 * stage 1+2), 1 k_striped stage-1/2 (hazard re-runs, long queries), 2 stage-3 alignment kernels,
-	 * 3 traceback kernels, 4 encode + hit extraction                                                     */
-	double  kernel_ms[5];
-	int64_t kernel_launches[5];
+	/* HIP-event time of the kernels, summed over launches (each on the stream it was launched on; with several
+	 * batches in flight the durations include sharing the GPU).  index: 0 k_scan (fused stage 1+2), 1 k_striped
+	 * stage-1/2 (hazard re-runs, long queries), 2 k_align_fwd, 3 k_finish_lds, 4 encode/hits/post/stream,
+	 * 5 k_striped stage 3 (exact replays, exact reverse passes), 6 k_finish (global scratch) + k_banded, 7 unused */
+	double  kernel_ms[8];
+	int64_t kernel_launches[8];
 	int64_t cells_stage1, cells_stage2, cells_stage3;   /* DP cells actually executed (stage 3: fwd + rev)   */
 	int64_t hazard_units;               /* units re-run by the stripe-faithful kernel (possible Q2)  */
 	int64_t rev_exact;                  /* window tries whose reverse pass ran on the stripe-faithful kernel */
