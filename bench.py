@@ -172,6 +172,15 @@ def main():
             bytes_per_unit, units_dom = agg["cells_stage3"] / m / calls + 5 * m + 24, calls
             cells_dom, ops_per_cell = agg["cells_stage3"], 6
         alg_bytes_per_launch = bytes_per_unit * units_dom / launches
+        # HBM traffic from the PMC passes (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate
+        # rocprofv3 --pmc runs, FETCH doubled per the gfx950 note), scaled to the units one launch of this build processes
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if dom == 0:
+                traffic = int(pmc["k_scan"]["hbm_bytes_per_unit"] * units_dom / launches)
+        except Exception:
+            traffic = None
         achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9
         out = {
             "metric": "SW Gcells/s (logical, whole job: stage 1+2+3 of the triplex scan)",
@@ -197,7 +206,7 @@ def main():
             "counts": {k: int(agg[k]) for k in ("segments", "units", "candidates", "align_calls", "hazard_units", "rev_exact",
                                                 "align_word_reruns", "stage2_overflow_units")},
             "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "avg_launch_ms": round(avg_ms, 3), "launches": int(launches),
                          "algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
                          "note": "integer DP is VALU-bound by construction; see valu"},
