@@ -82,7 +82,16 @@ struct FwdArgs {
 	const uint8_t* qcodes;
 	int32_t m, m_pad, seg_len16;
 	FwdOut* out;
+	int32_t vs, tile, ntiles;      // query tiling as in scan.hip
+	uint4* boundary;               // [stream position]: {hbot | fbot<<16, fpo | hazard<<16, key, 0} between tiles
 };
+
+__device__ __forceinline__ void lane_rows_a(int v, int seg_len, int vs, int* row0, int* rows)
+{
+	const int s = v / vs, j = v - s * vs, q = seg_len / vs, rem = seg_len - q * vs;
+	*rows = q + (j < rem ? 1 : 0);
+	*row0 = s * seg_len + j * q + (j < rem ? j : rem);
+}
 
 template <int RP>
 __global__ void __launch_bounds__(512) k_align_fwd(FwdArgs a)
@@ -94,9 +103,9 @@ __global__ void __launch_bounds__(512) k_align_fwd(FwdArgs a)
 		const int r = idx % AL_RS;
 		const int v = (idx / AL_RS) % 128;
 		const int t = idx / (AL_RS * 128);
-		const int vq = a.seg_len16 / 8, vrem = a.seg_len16 % 8, vj = v & 7;
-		const int rows_v = vq + (vj < vrem ? 1 : 0);
-		const int row = (v >> 3) * a.seg_len16 + vj * vq + (vj < vrem ? vj : vrem) + r;
+		int row0v, rows_v;
+		lane_rows_a(128 * a.tile + v, a.seg_len16, a.vs, &row0v, &rows_v);
+		const int row = row0v + r;
 		int sc = AL_NEG;
 		if (t < 5 && r < rows_v) {
 			if (row < a.m) { const int q = a.qcodes[row]; sc = ((q == t && t < 4) ? 5 : -4) * AL_SCALE; }
@@ -107,18 +116,18 @@ __global__ void __launch_bounds__(512) k_align_fwd(FwdArgs a)
 	__syncthreads();
 
 	// stripe-aligned layout (see scan.hip): virtual lane 8k starts the reference's stripe k
-	uint32_t fthr = 0xFFFFFFFFu, act = 0;
+	uint32_t fthr = 0xFFFFFFFFu, act = 0, startbits = 0;
 	int row0[2];
 	for (int h = 0; h < 2; h++) {
-		const int v = 2 * lane + h;
-		const int vq = a.seg_len16 / 8, vrem = a.seg_len16 % 8, vj = v & 7;
-		row0[h] = (v >> 3) * a.seg_len16 + vj * vq + (vj < vrem ? vj : vrem);
-		if (vj == 0 && v > 0) fthr = (fthr & ~(0xFFFFu << (16 * h))) | ((131u * AL_SCALE + (AL_SCALE - 1)) << (16 * h));
-		if (vrem == 0 || vj < vrem) act |= 0xFFFFu << (16 * h);
+		const int v = 128 * a.tile + 2 * lane + h;
+		int rows_v;
+		lane_rows_a(v, a.seg_len16, a.vs, &row0[h], &rows_v);
+		if (v % a.vs == 0 && v > 0) { fthr = (fthr & ~(0xFFFFu << (16 * h))) | ((131u * AL_SCALE + (AL_SCALE - 1)) << (16 * h)); startbits |= 0xFFFFu << (16 * h); }
+		if (rows_v == RP) act |= 0xFFFFu << (16 * h);
 	}
 	const v2u fthr2 = u_from((int)fthr);
 	const v2u actm = u_from((int)act);
-	const v2u startm = (v2u){ (unsigned short)(((2 * lane) & 7) == 0 && lane > 0 ? 0xFFFF : 0), 0 };
+	const v2u startm = u_from((int)startbits);
 	const bool lvl2 = a.seg_len16 >= 96;
 	const uint8_t* pl = prof + lane * AL_LANE_STRIDE;
 	// (31 - r) tags for the row keys, and the base of the global-row key of my two virtual lanes
@@ -135,6 +144,9 @@ __global__ void __launch_bounds__(512) k_align_fwd(FwdArgs a)
 		const FwdProb lastp = a.probs[p1 - 1];
 		const int slen = lastp.stream_off + lastp.len + 2 - s0;
 		const uint8_t* str = a.stream + s0;
+		uint4* bnd = a.boundary + s0;
+		const bool first_tile = a.tile == 0, last_tile = a.tile == a.ntiles - 1;
+		uint4 bchunk = make_uint4(0u, 0u, 0u, 0u);
 
 		v2s H[RP]; v2u E[RP];
 #pragma unroll
@@ -150,13 +162,22 @@ __global__ void __launch_bounds__(512) k_align_fwd(FwdArgs a)
 			if ((step & 63) == 0) {
 				const int c = step + lane;
 				chunk = c < slen ? (int)str[c] : CODE_VOID;
+				if (!first_tile) bchunk = c < slen ? bnd[c] : make_uint4(0u, 0u, 0u, 0u);
 			}
-			const int newcode = __builtin_amdgcn_readlane(chunk, step & 63);
+			int newcode = __builtin_amdgcn_readlane(chunk, step & 63);
+			int in_h = 0, in_f = 0, in_fp = 0, in_k = 0;
+			if (!first_tile) {
+				const uint32_t bx = (uint32_t)__builtin_amdgcn_readlane((int)bchunk.x, step & 63);
+				const uint32_t by = (uint32_t)__builtin_amdgcn_readlane((int)bchunk.y, step & 63);
+				in_k = __builtin_amdgcn_readlane((int)bchunk.z, step & 63);
+				in_h = (int)(bx << 16); in_f = (int)(bx & 0xffff0000u); in_fp = (int)(by << 16);
+				newcode |= (int)((by >> 16) & TAG_HZ);              // hazard seen by the tiles above
+			}
 			tc = vshift2(tc, newcode << 16);
-			const int recv_h = vshift2(hbot, 0);
-			const int recv_f = vshift2(fbot, 0);
-			const int recv_fp = vshift2(fpo, 0);
-			const uint32_t kup = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)khi, 0x138, 0xf, 0xf, false);
+			const int recv_h = vshift2(hbot, in_h);
+			const int recv_f = vshift2(fbot, in_f);
+			const int recv_fp = vshift2(fpo, in_fp);
+			const uint32_t kup = (uint32_t)__builtin_amdgcn_update_dpp(in_k, (int)khi, 0x138, 0xf, 0xf, false);
 			const uint32_t kin_lo = kup, kin_hi = klo;       // from virtual lane v-1 (same column, one step ago)
 			const int t_lo = tc & 7, t_hi = (tc >> 16) & 7;
 			const uint8_t* pa = pl + t_lo * AL_CODE_STRIDE;
@@ -238,7 +259,14 @@ __global__ void __launch_bounds__(512) k_align_fwd(FwdArgs a)
 			khi = kin_hi > loc_hi ? kin_hi : loc_hi;
 
 			// ---- pipe end: virtual lane 127 has just finished one column of the stream ---------------------
-			if (lane == 63) {
+			if (lane == 63 && !last_tile) {
+				// hand the bottom row of this tile to the next one (in place: this stream position was read 127 steps ago)
+				const int pos = step - 127;
+				if (pos >= 0 && pos < slen)
+					bnd[pos] = make_uint4(((uint32_t)hbot >> 16) | ((uint32_t)fbot & 0xffff0000u),
+						((uint32_t)fpo >> 16) | ((uint32_t)tc & 0xffff0000u), khi, 0u);
+			}
+			if (lane == 63 && last_tile) {
 				const int tag = (tc >> 16) & 0xff;
 				if ((tag & 7) != CODE_VOID) {
 					const int colmax = (int)(khi >> 16);
@@ -274,20 +302,28 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st)
 hipError_t launch_align_fwd(const FwdLaunch& L, hipStream_t st)
 {
 	if (L.ntask <= 0) return hipSuccess;
+	if (!systolic_fits(L.m)) return hipErrorInvalidValue;
 	FwdArgs a;
 	a.stream = L.stream; a.probs = L.probs; a.task_first = L.task_first; a.ntask = L.ntask; a.counter = L.counter;
 	a.qcodes = L.qcodes; a.m = L.m; a.m_pad = 16 * ((L.m + 15) / 16); a.seg_len16 = (L.m + 15) / 16; a.out = L.out;
-	if (a.seg_len16 < 8) return hipErrorInvalidValue;
-	switch ((a.seg_len16 + 7) / 8) {
-#define FASIM_FWD_CASE(N) case N: return launch_fwd_t<N>(a, st);
-	FASIM_FWD_CASE(1) FASIM_FWD_CASE(2) FASIM_FWD_CASE(3) FASIM_FWD_CASE(4) FASIM_FWD_CASE(5) FASIM_FWD_CASE(6)
-	FASIM_FWD_CASE(7) FASIM_FWD_CASE(8) FASIM_FWD_CASE(9) FASIM_FWD_CASE(10) FASIM_FWD_CASE(11) FASIM_FWD_CASE(12)
-	FASIM_FWD_CASE(13) FASIM_FWD_CASE(14) FASIM_FWD_CASE(15) FASIM_FWD_CASE(16) FASIM_FWD_CASE(17) FASIM_FWD_CASE(18)
-	FASIM_FWD_CASE(19) FASIM_FWD_CASE(20) FASIM_FWD_CASE(21) FASIM_FWD_CASE(22) FASIM_FWD_CASE(23) FASIM_FWD_CASE(24)
+	a.vs = systolic_vs(L.m); a.ntiles = a.vs / 8; a.boundary = L.boundary;
+	if (a.ntiles > 1 && !a.boundary) return hipErrorInvalidValue;
+	const int rp = (a.seg_len16 + a.vs - 1) / a.vs;
+	for (int t = 0; t < a.ntiles; t++) {
+		a.tile = t;
+		hipError_t err = hipErrorInvalidValue;
+		switch (rp) {
+#define FASIM_FWD_CASE(N) case N: err = launch_fwd_t<N>(a, st); break;
+		FASIM_FWD_CASE(1) FASIM_FWD_CASE(2) FASIM_FWD_CASE(3) FASIM_FWD_CASE(4) FASIM_FWD_CASE(5) FASIM_FWD_CASE(6)
+		FASIM_FWD_CASE(7) FASIM_FWD_CASE(8) FASIM_FWD_CASE(9) FASIM_FWD_CASE(10) FASIM_FWD_CASE(11) FASIM_FWD_CASE(12)
+		FASIM_FWD_CASE(13) FASIM_FWD_CASE(14) FASIM_FWD_CASE(15) FASIM_FWD_CASE(16) FASIM_FWD_CASE(17) FASIM_FWD_CASE(18)
+		FASIM_FWD_CASE(19) FASIM_FWD_CASE(20) FASIM_FWD_CASE(21) FASIM_FWD_CASE(22) FASIM_FWD_CASE(23) FASIM_FWD_CASE(24)
 #undef FASIM_FWD_CASE
-	default: break;
+		default: break;
+		}
+		if (err != hipSuccess) return err;
 	}
-	return hipErrorInvalidValue;
+	return hipSuccess;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -367,8 +403,9 @@ __global__ void __launch_bounds__(64) k_finish(const uint8_t* __restrict__ tcode
 	const uint8_t* tw = tcodes + pb.tbase;
 	int ref_begin = fo.ref_begin, read_begin = fo.read_begin;
 	if (!(fo.flags & 2)) {
-		// below 148 no F of the reverse pass can reach 132, so the signed lazy-F exit (Q2) cannot fire there
-		if (fo.score >= 148) { o->status = 11; return; }
+		// below 148 no F of the reverse pass can reach 132, so the signed lazy-F exit (Q2) cannot fire there; from 251 on
+		// the reference uses its 16-bit kernels, whose compare is not affected
+		if (fo.score >= 148 && fo.score < 255 - BIAS) { o->status = 11; return; }
 		int32_t* Gp = reinterpret_cast<int32_t*>(my);
 		int32_t* Ep = Gp + G_ROWS;
 		if (reverse_pass(tw, qcodes, fo.score, fo.ref_end, fo.read_end, Gp, Ep, &ref_begin, &read_begin)) { o->status = 11; return; }
@@ -560,7 +597,9 @@ __global__ void __launch_bounds__(64) k_finish_lds(const uint8_t* __restrict__ t
 	const uint8_t* tw = tcodes + pb.tbase;
 	int ref_begin = fo.ref_begin, read_begin = fo.read_begin;
 	if (!(fo.flags & 2)) {
-		if (fo.score >= 148) { o->status = 11; return; }
+		// 148..250: an F >= 132 is possible in the reverse pass of the 8-bit kernel; >= 251 runs on the reference's
+		// 16-bit kernels, whose compare is not affected
+		if (fo.score >= 148 && fo.score < 255 - BIAS) { o->status = 11; return; }
 		const int r = reverse_pass_lds(tw, qcodes, fo.score, fo.ref_end, fo.read_end, A, &ref_begin, &read_begin);
 		if (r) { o->status = r == 2 ? 2 : 11; return; }
 	}

@@ -72,7 +72,7 @@ struct fasim_engine {
 	ScoreLut lut1, lut2;
 	DevBuf q1, q2, enc_lut, counter, dna, seg_start, seg_len, enc_ids, tcodes, colmax, probs, max_out, unit_len,
 		stage1, hits, hits_total, hit_off, hit_cnt, thr, ends, bprobs, bout, scratch, colmax16, unit_ids, flags, stage1_in, hits2,
-		fprobs, ftasks, fstream, fout, aout, cigpool, cigcount, forder, scratch2;
+		fprobs, ftasks, fstream, fout, aout, cigpool, cigcount, forder, scratch2, boundary, fboundary;
 	bool align_v1 = false;        // FASIM_ALIGN_V1=1: force the stripe-faithful kernels for stage 3
 	std::vector<fasim_engine*> workers;   // extra engines on the same device: batches in flight concurrently
 	int host_threads_total = 1;
@@ -260,6 +260,11 @@ int run_scan_v2(fasim_engine* E, const UnitBatch& B, const std::vector<char>& un
 	ScanLaunch L;
 	L.tcodes = E->tcodes.as<uint8_t>(); L.unit_len = E->unit_len.as<int32_t>(); L.tstride = B.tstride;
 	L.counter = E->counter.as<uint32_t>(); L.m = E->m; L.colmax16 = E->colmax16.as<uint16_t>();
+	L.boundary = nullptr;
+	if (systolic_fits(E->m) && systolic_tiles(E->m) > 1) {
+		HIPOK(E->boundary.ensure((size_t)nu * B.tstride * sizeof(uint2)));
+		L.boundary = E->boundary.as<uint2>();
+	}
 	hipError_t he;
 	if (!sep.empty()) {
 		// units whose segment holds N (or every unit, when the query has letters outside ACGT): the stage-1
@@ -353,6 +358,8 @@ struct WindowProb { int unit, t0, len; };
 
 int run_finish(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, const std::vector<FwdOut>& fo,
 	std::vector<AlignResult>& out, std::vector<uint32_t>& cigars, std::vector<char>& status);
+bool align_v2_fits(const fasim_engine* E, const std::vector<WindowProb>& W);
+int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, std::vector<FwdOut>& fo);
 
 // a9-a11: ssw_align for a list of windows (forward + reverse on the GPU, 16-bit re-runs, banded traceback)
 int run_align(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, std::vector<AlignResult>& out,
@@ -375,16 +382,31 @@ int run_align(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>
 	HIPOK(hipStreamSynchronize(E->st));
 	std::vector<int> redo;
 	for (int k = 0; k < n; k++) if (ends[k].score_fwd == 255) redo.push_back(k);
+	std::vector<char> from_sys(n, 0);        // forward result taken from the systolic kernel (16-bit semantics)
 	if (!redo.empty()) {
-		// bests[0].score == 255 -> the whole alignment is redone with the 16-bit kernels (sswNew.cpp:1473-1477)
-		std::vector<StripedProb> wp(redo.size());
-		for (size_t r = 0; r < redo.size(); r++) { wp[r] = probs[redo[r]]; wp[r].unit = (int)r; }
-		rc = run_striped(E, MODE_ALIGN, true, wp, false, E->tcodes.as<uint8_t>(), E->m);
-		if (rc) return rc;
-		std::vector<AlignEnds> we(redo.size());
-		HIPOK(hipMemcpyAsync(we.data(), E->ends.p, sizeof(AlignEnds) * redo.size(), hipMemcpyDeviceToHost, E->st));
-		HIPOK(hipStreamSynchronize(E->st));
-		for (size_t r = 0; r < redo.size(); r++) ends[redo[r]] = we[r];
+		// bests[0].score == 255 -> the whole alignment is redone with the 16-bit kernels (sswNew.cpp:1473-1477), which have
+		// no overflow rule and no signed-compare problem: their result is the textbook one
+		std::vector<WindowProb> W2(redo.size());
+		for (size_t r = 0; r < redo.size(); r++) W2[r] = W[redo[r]];
+		if (align_v2_fits(E, W2)) {
+			std::vector<FwdOut> f2;
+			rc = run_fwd(E, B, W2, f2); if (rc) return rc;
+			for (size_t r = 0; r < redo.size(); r++) {
+				AlignEnds& e = ends[redo[r]];
+				e.score_fwd = f2[r].score; e.ref_end = f2[r].ref_end; e.read_end = f2[r].read_end;
+				e.score_rev = f2[r].score; e.ref_begin = 0; e.read_begin = 0;
+				from_sys[redo[r]] = 1;
+			}
+		} else {
+			std::vector<StripedProb> wp(redo.size());
+			for (size_t r = 0; r < redo.size(); r++) { wp[r] = probs[redo[r]]; wp[r].unit = (int)r; }
+			rc = run_striped(E, MODE_ALIGN, true, wp, false, E->tcodes.as<uint8_t>(), E->m);
+			if (rc) return rc;
+			std::vector<AlignEnds> we(redo.size());
+			HIPOK(hipMemcpyAsync(we.data(), E->ends.p, sizeof(AlignEnds) * redo.size(), hipMemcpyDeviceToHost, E->st));
+			HIPOK(hipStreamSynchronize(E->st));
+			for (size_t r = 0; r < redo.size(); r++) ends[redo[r]] = we[r];
+		}
 		if (stats) stats->align_word_reruns += (int64_t)redo.size();
 	}
 	// banded traceback for every alignment with a positive score
@@ -414,7 +436,7 @@ int run_align(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>
 		for (size_t i = 0; i < bp.size(); i++) {
 			const int k = bidx[i]; const AlignEnds& e = ends[k];
 			W2[i] = W[k];
-			f2[i].score = bp[i].score; f2[i].ref_end = e.ref_end; f2[i].read_end = e.read_end; f2[i].flags = 2;
+			f2[i].score = bp[i].score; f2[i].ref_end = e.ref_end; f2[i].read_end = e.read_end; f2[i].flags = from_sys[k] ? 0 : 2;
 			f2[i].ref_begin = e.ref_begin; f2[i].read_begin = e.read_begin;
 		}
 		std::vector<char> fst;
@@ -464,7 +486,12 @@ int run_align(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>
 		if (bo[i].status != 0) { r.sw_score = 0; continue; }    // NULL from ssw_align -> sw_score 0 (ssw_cpp.cpp:631-633)
 		r.sw_score = bp[i].score; r.ref_begin = e.ref_begin; r.ref_end = e.ref_end;
 		r.query_begin = e.read_begin; r.query_end = e.read_end;
-		if (via_finish[i]) { r.cigar_len = fres[i].cigar_len; r.cigar_off = fres[i].cigar_off; if (fres[i].sw_score <= 0) r.sw_score = 0; continue; }
+		if (via_finish[i]) {
+			r.cigar_len = fres[i].cigar_len; r.cigar_off = fres[i].cigar_off;
+			if (from_sys[k]) { r.ref_begin = fres[i].ref_begin; r.query_begin = fres[i].query_begin; }
+			if (fres[i].sw_score <= 0) r.sw_score = 0;
+			continue;
+		}
 		r.cigar_len = bo[i].cigar_len;
 		r.cigar_off = (uint32_t)cigars.size();
 		cigars.insert(cigars.end(), bo[i].cigar, bo[i].cigar + bo[i].cigar_len);
@@ -475,8 +502,7 @@ int run_align(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>
 // ---- stage 3 through align.hip ---------------------------------------------------------------------
 bool align_v2_fits(const fasim_engine* E, const std::vector<WindowProb>& W)
 {
-	const int seg16 = (E->m + 15) / 16;
-	if (E->align_v1 || seg16 < 8 || seg16 > 192) return false;      // 128 virtual lanes x up to 24 rows
+	if (E->align_v1 || !systolic_fits(E->m)) return false;
 	for (const WindowProb& w : W) if (w.len > 200 || w.len <= 0) return false;
 	return true;
 }
@@ -511,6 +537,8 @@ int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& 
 	L.stream = E->fstream.as<uint8_t>(); L.probs = E->fprobs.as<FwdProb>(); L.task_first = E->ftasks.as<int32_t>();
 	L.ntask = (int)tasks.size() - 1; L.counter = E->counter.as<uint32_t>(); L.qcodes = E->q2.as<uint8_t>(); L.m = E->m;
 	L.out = E->fout.as<FwdOut>();
+	L.boundary = nullptr;
+	if (systolic_tiles(E->m) > 1) { HIPOK(E->fboundary.ensure(((size_t)off + 256) * sizeof(uint4))); L.boundary = E->fboundary.as<uint4>(); }
 	{ TimedScope ts(E, 2); he = launch_align_fwd(L, E->st); }
 	if (he != hipSuccess) return fail(E, FASIM_E_HIP, "align_fwd launch failed: %s", hipGetErrorString(he));
 	tp = now_s();
@@ -734,7 +762,7 @@ void fasim_engine_destroy(fasim_engine* e)
 	DevBuf* bufs[] = { &e->q1, &e->q2, &e->enc_lut, &e->counter, &e->dna, &e->seg_start, &e->seg_len, &e->enc_ids, &e->tcodes,
 		&e->colmax, &e->probs, &e->max_out, &e->unit_len, &e->stage1, &e->hits, &e->hits_total, &e->hit_off, &e->hit_cnt, &e->thr,
 		&e->ends, &e->bprobs, &e->bout, &e->scratch, &e->dna_res, &e->colmax16, &e->unit_ids, &e->flags, &e->stage1_in, &e->hits2,
-		&e->fprobs, &e->ftasks, &e->fstream, &e->fout, &e->aout, &e->cigpool, &e->cigcount, &e->forder, &e->scratch2 };
+		&e->fprobs, &e->ftasks, &e->fstream, &e->fout, &e->aout, &e->cigpool, &e->cigcount, &e->forder, &e->scratch2, &e->boundary, &e->fboundary };
 	for (auto& t : e->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
 	for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
 	for (DevBuf* b : bufs) b->release();

@@ -42,7 +42,11 @@ hipError_t launch_banded(const uint8_t* tcodes, const uint8_t* qcodes, const Ban
 struct ScanLaunch {
 	const uint8_t* tcodes; const int32_t* unit_ids; const int32_t* unit_len; int32_t nwork; int32_t tstride;
 	uint32_t* counter; const uint8_t* qcodes; int32_t m; int8_t score[25]; uint16_t* colmax16;
+	uint2* boundary;      // [unit][tstride] hand-over rows between query tiles; needed when systolic_tiles(m) > 1
 };
+int systolic_vs(int m);
+int systolic_tiles(int m);     // query tiles of 128 virtual lanes x <= 24 rows (1 for m <= 3072)
+bool systolic_fits(int m);
 hipError_t launch_scan(const ScanLaunch& L, hipStream_t st);      // hipErrorInvalidValue: query too long for this kernel
 hipError_t launch_scan_post(const uint16_t* colmax16, const int32_t* unit_ids, int32_t nwork, const int32_t* unit_len,
 	int32_t tstride, const int32_t* stage1_in, uint32_t* hits, uint32_t hits_cap, uint32_t* hits_total, int32_t* hit_off,
@@ -54,6 +58,7 @@ hipError_t launch_max16(const uint16_t* colmax16, const int32_t* unit_ids, int32
 struct FwdLaunch {
 	const uint8_t* stream; const FwdProb* probs; const int32_t* task_first; int32_t ntask; uint32_t* counter;
 	const uint8_t* qcodes; int32_t m; FwdOut* out;
+	uint4* boundary;      // [stream position] hand-over between query tiles; needed when systolic_tiles(m) > 1
 };
 hipError_t launch_build_stream(const uint8_t* tcodes, const FwdProb* probs, int32_t nprob, uint8_t* stream, hipStream_t st);
 hipError_t launch_align_fwd(const FwdLaunch& L, hipStream_t st);     // hipErrorInvalidValue: query too long

@@ -341,8 +341,12 @@ static hipError_t launch_striped_t(const StripedLaunch& L, hipStream_t st)
 	int s4 = (segLen + 3) & ~3;
 	if (((s4 / 4) & 1) == 0) s4 += 4;          // odd dword stride between stripes: conflict-free LDS rows
 	const size_t gbytes = (size_t)(WORD ? 80 : 48) * s4;
-	const size_t shmem = 4 * gbytes;
-	if (shmem > 160 * 1024) return hipErrorInvalidValue;   // query too long for the LDS-resident kernel
+	// up to four 16-lane groups (problems) per one-wave workgroup; long queries get fewer groups so that one group's
+	// H/E/query stripes still fit the 160 KB of LDS
+	int groups = (int)((160 * 1024) / gbytes);
+	if (groups > 4) groups = 4;
+	if (groups < 1) return hipErrorInvalidValue;           // query too long for the LDS-resident kernel
+	const size_t shmem = (size_t)groups * gbytes;
 	auto kern = k_striped<MODE, WORD, QUIRK>;
 	hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
 	if (err != hipSuccess) return err;
@@ -351,16 +355,22 @@ static hipError_t launch_striped_t(const StripedLaunch& L, hipStream_t st)
 	StripedArgs a;
 	a.tcodes = L.tcodes; a.qcodes = L.qcodes; a.probs = L.probs; a.nprob = L.nprob; a.counter = L.counter;
 	a.lut = L.lut; a.s4 = s4; a.colmax = L.colmax; a.max_out = L.max_out; a.ends = L.ends;
-	// enough 1-wave workgroups to fill the chip at the LDS-limited occupancy; the queue balances the rest
-	int per_cu = (int)((160 * 1024) / (shmem ? shmem : 1));
+	// enough one-wave workgroups to fill the chip at the LDS-limited occupancy; the queue balances the rest
+	int per_cu = (int)((160 * 1024) / shmem);
 	if (per_cu < 1) per_cu = 1;
 	if (per_cu > 16) per_cu = 16;
 	long blocks = (long)256 * per_cu;
-	const long need = ((long)L.nprob + 3) / 4;
+	const long need = ((long)L.nprob + groups - 1) / groups;
 	if (blocks > need) blocks = need;
+	hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3((unsigned)(16 * groups)), shmem, st, a);
+	return hipGetLastError();
+}
+
+#if 0
 	hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), shmem, st, a);
 	return hipGetLastError();
 }
+#endif
 
 hipError_t launch_striped(StripedMode mode, bool word, bool quirk, const StripedLaunch& a, hipStream_t st)
 {

@@ -64,7 +64,20 @@ struct ScanArgs {
 	int32_t seg_len16;           // ceil(m/16): stripe length of the reference's byte kernels
 	int8_t score[25];            // score[t*5+q]
 	uint16_t* colmax16;          // [unit][tstride] : bit 15 = hazard, bits 0..14 = column maximum
+	int32_t vs;                  // virtual lanes per reference stripe (multiple of 8): 16*vs virtual lanes in all
+	int32_t tile;                // this launch handles virtual lanes [128*tile, 128*tile+128)
+	int32_t ntiles;
+	uint2* boundary;             // [unit][tstride]: per column {hbot | fbot<<16, cm | fpo<<16} handed from tile to tile
 };
+
+// rows owned by global virtual lane v (stripe-aligned layout): stripe s = v / vs gets its ceil(m/16) rows spread over
+// vs virtual lanes, the first (segLen % vs) of them one row longer
+__device__ __forceinline__ void lane_rows(int v, int seg_len, int vs, int* row0, int* rows)
+{
+	const int s = v / vs, j = v - s * vs, q = seg_len / vs, rem = seg_len - q * vs;
+	*rows = q + (j < rem ? 1 : 0);
+	*row0 = s * seg_len + j * q + (j < rem ? j : rem);
+}
 
 template <int RP>
 __global__ void __launch_bounds__(256) k_scan(ScanArgs a)
@@ -77,11 +90,11 @@ __global__ void __launch_bounds__(256) k_scan(ScanArgs a)
 		const int r = idx % SCAN_RS;
 		const int v = (idx / SCAN_RS) % 128;
 		const int t = idx / (SCAN_RS * 128);
-		// stripe-aligned layout: the reference's stripe s = rows [s*segLen, (s+1)*segLen) is spread over the 8
-		// virtual lanes 8s..8s+7, so every stripe boundary is a virtual-lane boundary
-		const int vq = a.seg_len16 / 8, vrem = a.seg_len16 % 8, vj = v & 7;
-		const int rows_v = vq + (vj < vrem ? 1 : 0);
-		const int row = (v >> 3) * a.seg_len16 + vj * vq + (vj < vrem ? vj : vrem) + r;
+		// stripe-aligned layout: the reference's stripe s = rows [s*segLen, (s+1)*segLen) is spread over `vs` virtual
+		// lanes, so every stripe boundary is a virtual-lane boundary; this launch stages the rows of its tile only
+		int row0, rows_v;
+		lane_rows(128 * a.tile + v, a.seg_len16, a.vs, &row0, &rows_v);
+		const int row = row0 + r;
 		int sc = SCAN_DEAD;
 		if (r < rows_v) {
 			if (row < a.m) sc = a.score[t * 5 + a.qcodes[row]];
@@ -95,17 +108,18 @@ __global__ void __launch_bounds__(256) k_scan(ScanArgs a)
 	// fthr: a half whose virtual lane starts a stripe (v = 8k, k >= 1) sees F[b] of the boundary row b directly as
 	//       its incoming F; Q2 needs F[b] >= 132 (131 = "greater than" threshold), other halves never flag.
 	// act : 0xFFFF where the half owns RP rows, 0 where it owns RP-1 (its last register row is transparent)
-	uint32_t fthr = 0xFFFFFFFFu, act = 0;
+	uint32_t fthr = 0xFFFFFFFFu, act = 0, startbits = 0;
 	for (int h = 0; h < 2; h++) {
-		const int v = 2 * lane + h;
-		if ((v & 7) == 0 && v > 0) fthr = (fthr & ~(0xFFFFu << (16 * h))) | (131u << (16 * h));
-		const int vrem = a.seg_len16 % 8;
-		if (vrem == 0 || (v & 7) < vrem) act |= 0xFFFFu << (16 * h);
+		const int v = 128 * a.tile + 2 * lane + h;        // global virtual lane
+		int row0, rows_v;
+		lane_rows(v, a.seg_len16, a.vs, &row0, &rows_v);
+		if (v % a.vs == 0 && v > 0) { fthr = (fthr & ~(0xFFFFu << (16 * h))) | (131u << (16 * h)); startbits |= 0xFFFFu << (16 * h); }
+		if (rows_v == RP) act |= 0xFFFFu << (16 * h);
 	}
 	const v2u fthr2 = __builtin_bit_cast(v2u, fthr);
 	const v2u actm = __builtin_bit_cast(v2u, act);
-	// stripe-start halves (v = 8k, k >= 1) take the crossing F as the start of a propagation chain
-	const v2u startm = (v2u){ (unsigned short)(((2 * lane) & 7) == 0 && lane > 0 ? 0xFFFF : 0), 0 };
+	// stripe-start halves take the crossing F as the start of a propagation chain
+	const v2u startm = __builtin_bit_cast(v2u, startbits);
 	// the refined test needs F to die inside one stripe (F <= 234 decays by 4 per row)
 	const bool lvl2 = a.seg_len16 >= 96;
 	const uint8_t* pl = prof + lane * SCAN_LANE_STRIDE;
@@ -119,6 +133,9 @@ __global__ void __launch_bounds__(256) k_scan(ScanArgs a)
 		const int n = a.unit_len[unit];
 		const uint8_t* tc_unit = a.tcodes + (int64_t)unit * a.tstride;
 		uint16_t* out = a.colmax16 + (int64_t)unit * a.tstride;
+		uint2* bnd = a.boundary + (int64_t)unit * a.tstride;
+		const bool first_tile = a.tile == 0, last_tile = a.tile == a.ntiles - 1;
+		uint2 bchunk = make_uint2(0u, 0u);
 
 		v2s H[RP]; v2u E[RP];
 #pragma unroll
@@ -131,14 +148,21 @@ __global__ void __launch_bounds__(256) k_scan(ScanArgs a)
 			if ((step & 63) == 0) {
 				const int c = step + lane;
 				chunk = c < n ? (int)tc_unit[c] : CODE_N;
+				if (!first_tile) bchunk = c < n ? bnd[c] : make_uint2(0u, 0u);     // bottom row of the previous tile
 			}
 			const int newcode = __builtin_amdgcn_readlane(chunk, step & 63);
-			// hand-over from virtual lane v-1 (computed one step ago)
+			int in_h = 0, in_f = 0, in_cm = 0, in_fp = 0;
+			if (!first_tile) {
+				const uint32_t bx = (uint32_t)__builtin_amdgcn_readlane((int)bchunk.x, step & 63);
+				const uint32_t by = (uint32_t)__builtin_amdgcn_readlane((int)bchunk.y, step & 63);
+				in_h = (int)(bx << 16); in_f = (int)(bx & 0xffff0000u); in_cm = (int)(by << 16); in_fp = (int)(by & 0xffff0000u);
+			}
+			// hand-over from virtual lane v-1 (computed one step ago; lane 0 takes the previous tile's bottom row)
 			tc = vshift(tc, newcode << 16);
-			const int recv_h = vshift(hbot, 0);
-			const int recv_f = vshift(fbot, 0);
-			const int recv_cm = vshift(cm, 0);
-			const int recv_fp = vshift(fpo, 0);
+			const int recv_h = vshift(hbot, in_h);
+			const int recv_f = vshift(fbot, in_f);
+			const int recv_cm = vshift(cm, in_cm);
+			const int recv_fp = vshift(fpo, in_fp);
 			const int t_lo = tc & 0xff, t_hi = (tc >> 16) & 0xff;
 			const uint8_t* pa = pl + t_lo * SCAN_CODE_STRIDE;
 			const uint8_t* pb = pl + t_hi * SCAN_CODE_STRIDE + 48;
@@ -214,7 +238,10 @@ __global__ void __launch_bounds__(256) k_scan(ScanArgs a)
 			const v2u cval = __builtin_elementwise_max(cin & (v2u){ 0x7fff, 0x7fff }, as_u(lmax));
 			cm = to_int(cval | ((cin | hz) & (v2u){ 0x8000, 0x8000 }));
 			const int cdone = step - 127;
-			if (lane == 63 && cdone >= 0) out[cdone] = (uint16_t)((uint32_t)cm >> 16);
+			if (lane == 63 && cdone >= 0) {
+				if (last_tile) out[cdone] = (uint16_t)((uint32_t)cm >> 16);
+				else bnd[cdone] = make_uint2(((uint32_t)hbot >> 16) | ((uint32_t)fbot & 0xffff0000u), ((uint32_t)cm >> 16) | ((uint32_t)fpo & 0xffff0000u));
+			}
 		}
 	}
 }
@@ -231,26 +258,41 @@ static hipError_t launch_scan_t(const ScanArgs& a, hipStream_t st)
 	return hipGetLastError();
 }
 
+// virtual lanes per reference stripe for a query of m rows: a multiple of 8 (so that a tile of 128 virtual lanes is
+// always full) with at most 24 rows per virtual lane
+int systolic_vs(int m) { const int seg = (m + 15) / 16; return 8 * ((seg + 191) / 192); }
+int systolic_tiles(int m) { return systolic_vs(m) / 8; }
+bool systolic_fits(int m) { const int seg = (m + 15) / 16; return seg >= 8 && systolic_tiles(m) <= 16; }
+
 hipError_t launch_scan(const ScanLaunch& L, hipStream_t st)
 {
 	if (L.nwork <= 0) return hipSuccess;
+	if (!systolic_fits(L.m)) return hipErrorInvalidValue;      // tiny or huge queries: striped kernels
 	ScanArgs a;
 	a.tcodes = L.tcodes; a.unit_ids = L.unit_ids; a.unit_len = L.unit_len; a.nwork = L.nwork; a.tstride = L.tstride;
 	a.counter = L.counter; a.qcodes = L.qcodes; a.m = L.m; a.m_pad = 16 * ((L.m + 15) / 16); a.seg_len16 = (L.m + 15) / 16;
 	for (int i = 0; i < 25; i++) a.score[i] = L.score[i];
 	a.colmax16 = L.colmax16;
-	if (a.seg_len16 < 8) return hipErrorInvalidValue;      // tiny queries: striped kernels
-	// RP must be exactly ceil(segLen/8): every virtual lane then owns RP or RP-1 rows
-	switch ((a.seg_len16 + 7) / 8) {
-#define FASIM_SCAN_CASE(N) case N: return launch_scan_t<N>(a, st);
-	FASIM_SCAN_CASE(1) FASIM_SCAN_CASE(2) FASIM_SCAN_CASE(3) FASIM_SCAN_CASE(4) FASIM_SCAN_CASE(5) FASIM_SCAN_CASE(6)
-	FASIM_SCAN_CASE(7) FASIM_SCAN_CASE(8) FASIM_SCAN_CASE(9) FASIM_SCAN_CASE(10) FASIM_SCAN_CASE(11) FASIM_SCAN_CASE(12)
-	FASIM_SCAN_CASE(13) FASIM_SCAN_CASE(14) FASIM_SCAN_CASE(15) FASIM_SCAN_CASE(16) FASIM_SCAN_CASE(17) FASIM_SCAN_CASE(18)
-	FASIM_SCAN_CASE(19) FASIM_SCAN_CASE(20) FASIM_SCAN_CASE(21) FASIM_SCAN_CASE(22) FASIM_SCAN_CASE(23) FASIM_SCAN_CASE(24)
+	a.vs = systolic_vs(L.m); a.ntiles = a.vs / 8; a.boundary = L.boundary;
+	if (a.ntiles > 1 && !a.boundary) return hipErrorInvalidValue;
+	// RP must be exactly ceil(segLen/vs): every virtual lane then owns RP or RP-1 rows.  One launch per tile of 128
+	// virtual lanes (long queries): tile t reads the bottom row tile t-1 left in `boundary` and overwrites it in place.
+	const int rp = (a.seg_len16 + a.vs - 1) / a.vs;
+	for (int t = 0; t < a.ntiles; t++) {
+		a.tile = t;
+		hipError_t err = hipErrorInvalidValue;
+		switch (rp) {
+#define FASIM_SCAN_CASE(N) case N: err = launch_scan_t<N>(a, st); break;
+		FASIM_SCAN_CASE(1) FASIM_SCAN_CASE(2) FASIM_SCAN_CASE(3) FASIM_SCAN_CASE(4) FASIM_SCAN_CASE(5) FASIM_SCAN_CASE(6)
+		FASIM_SCAN_CASE(7) FASIM_SCAN_CASE(8) FASIM_SCAN_CASE(9) FASIM_SCAN_CASE(10) FASIM_SCAN_CASE(11) FASIM_SCAN_CASE(12)
+		FASIM_SCAN_CASE(13) FASIM_SCAN_CASE(14) FASIM_SCAN_CASE(15) FASIM_SCAN_CASE(16) FASIM_SCAN_CASE(17) FASIM_SCAN_CASE(18)
+		FASIM_SCAN_CASE(19) FASIM_SCAN_CASE(20) FASIM_SCAN_CASE(21) FASIM_SCAN_CASE(22) FASIM_SCAN_CASE(23) FASIM_SCAN_CASE(24)
 #undef FASIM_SCAN_CASE
-	default: break;
+		default: break;
+		}
+		if (err != hipSuccess) return err;
 	}
-	return hipErrorInvalidValue;         // query longer than 3072 rows: caller uses the striped kernels
+	return hipSuccess;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -120,6 +120,25 @@ def test_q2_units_scan(mod, engine, h19, golden_dir):
     assert mod.tfosorted(res, chro, start, p) == open(os.path.join(golden_dir, "q2cat.TFOsorted"), "rb").read()
 
 
+@pytest.mark.parametrize("name", ["meg3", "malat1", "neat1"])
+def test_long_queries_scan(mod, engine, golden_dir, name):
+    """MEG3 (1 582 nt, 1 query tile), MALAT1 (8 708 nt, 3 tiles) and NEAT1 (22 767 nt, 8 tiles): the systolic kernels run
+    one launch per tile of 128 virtual lanes and hand the bottom row over through HBM."""
+    _, rna = synth.read_fasta(os.path.join(golden_dir, name.upper() + ".fa"))
+    hdr, dna = synth.read_fasta(os.path.join(golden_dir, name + "_dna.fa"))
+    _, units = helpers.parse_scan(helpers.gunzip(os.path.join(golden_dir, name + ".scan.gz")))
+    engine.set_query(rna)
+    res = engine.scan(dna, mod.default_params(cLength=20))
+    assert res.stats["units"] == len(units)
+    assert res.stats["candidates"] == sum(u["ncand"] for u in units)
+    assert res.triplexes() == _expected_triplexes(units)
+    assert res.stats["kernel_launches"][0] > 0, "the systolic scan kernel must have run"
+    p = mod.default_params(cLength=40)
+    res = engine.scan(dna, p)
+    _, chro, start = mod.parse_dna_header(hdr)
+    assert mod.tfosorted(res, chro, start, p) == open(os.path.join(golden_dir, name + ".TFOsorted"), "rb").read()
+
+
 def test_systolic_and_stripe_faithful_paths_agree(mod, h19, golden_dir, monkeypatch):
     """FASIM_SCAN_V1 / FASIM_ALIGN_V1 force the stripe-faithful kernels everywhere; records must be identical."""
     _, dna = synth.read_fasta(os.path.join(golden_dir, "planted40k.fa"))

@@ -96,3 +96,14 @@ def test_q2_units_fixture(oracle_build, golden_dir):
     b = (ctypes.c_int * len(t))()
     o.lib.fo_pre_align_noq2(q, len(q), t, len(t), b)
     assert o.pre_align(q, t) != list(b)
+
+
+@pytest.mark.parametrize("name", ["meg3", "malat1"])
+def test_long_queries(oracle_build, golden_dir, name):
+    """The reference's example lncRNAs MEG3 (1 582 nt) and MALAT1 (8 708 nt) against planted synthetic DNA."""
+    rna = os.path.join(golden_dir, name.upper() + ".fa")
+    dna = os.path.join(golden_dir, name + "_dna.fa")
+    out = helpers.oracle_cli(oracle_build, "scan", rna, dna, "-detail", "0", "-threads", "8")
+    assert out == helpers.gunzip(os.path.join(golden_dir, name + ".scan.gz"))
+    out = helpers.oracle_cli(oracle_build, "tfosorted", rna, dna, "-lg", "40", "-threads", "8")
+    assert out == open(os.path.join(golden_dir, name + ".TFOsorted"), "rb").read()
