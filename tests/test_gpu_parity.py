@@ -227,3 +227,22 @@ def test_live_reference_probe_random_vectors(engine, oracle_build):
         else:
             assert (a.sw_score, a.ref_begin, a.ref_end, a.query_begin, a.query_end) == tuple(int(x) for x in g[1:6])
             assert (a.cigar_string() or "*") == g[6]
+
+
+def test_live_reference_10kb_query_ntmax(mod, engine, tmp_path):
+    """BASELINE config 5 in miniature: a 10 kb synthetic lncRNA (4 query tiles), -na 1000, planted DNA so that byte
+    overflows and 16-bit re-runs occur; compared with the compiled reference when it travelled with the repo."""
+    if not helpers.have_ref_probe():
+        pytest.skip("oracle/_ref/ref_probe not present")
+    rna = synth.random_rna(10000, 515)
+    dna = synth.planted_dna(12000, 516, rna, every=500, max_len=180, mut_pct=6)
+    (tmp_path / "rna.fa").write_bytes(b">syn10k\n" + rna + b"\n")
+    (tmp_path / "dna.fa").write_bytes(b">syn|chrT|1-12000\n" + dna + b"\n")
+    out = subprocess.run([helpers.REF_PROBE, "scan", "rna.fa", "dna.fa", "-detail", "0", "-na", "1000"], cwd=tmp_path, check=True,
+                         stdout=subprocess.PIPE).stdout
+    _, units = helpers.parse_scan(out)
+    engine.set_query(rna)
+    res = engine.scan(dna, mod.default_params(cLength=20, ntMax=1000))
+    assert res.stats["candidates"] == sum(u["ncand"] for u in units)
+    assert res.triplexes() == _expected_triplexes(units)
+    assert sum(u["stage1"] >= 251 for u in units) > 0, "the case must exercise byte overflow"
