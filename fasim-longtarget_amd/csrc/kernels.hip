@@ -205,11 +205,14 @@ __global__ void __launch_bounds__(64) k_striped(StripedArgs a)
 	const int g = threadIdx.x >> 4;
 	const int s = threadIdx.x & 15;
 	const int S4 = a.s4;
-	const size_t gbytes = (size_t)(WORD ? 80 : 48) * S4;
+	// MODE_PRE / MODE_MAX1: every problem of the launch aligns the same whole query, so its striped copy is shared by
+	// the groups of the workgroup (placed after the per-group H/E regions); the alignment modes need one per group
+	constexpr bool SHARED_Q = (MODE == MODE_PRE || MODE == MODE_MAX1);
+	const size_t gbytes = (size_t)(SHARED_Q ? (WORD ? 64 : 32) : (WORD ? 80 : 48)) * S4;
 	uint8_t* base = lds + g * gbytes;
 	HT* Hs = reinterpret_cast<HT*>(base) + (size_t)s * S4;
 	HT* Es = reinterpret_cast<HT*>(base) + (size_t)16 * S4 + (size_t)s * S4;
-	uint8_t* Qs = base + (size_t)(WORD ? 64 : 32) * S4 + (size_t)s * S4;
+	uint8_t* Qs = (SHARED_Q ? lds + (blockDim.x >> 4) * gbytes : base + (size_t)(WORD ? 64 : 32) * S4) + (size_t)s * S4;
 	const bool part = s < P;
 	const uint32_t l0 = a.lut.row[0], l1 = a.lut.row[1], l2 = a.lut.row[2], l3 = a.lut.row[3], l4 = a.lut.row[4];
 
@@ -217,7 +220,7 @@ __global__ void __launch_bounds__(64) k_striped(StripedArgs a)
 	int pi = 0, unit = 0, t0 = 0, refLen = 0, qlen = 0, dir = 0, terminate = 0, segLen = 1;
 	int ci = 0, maxv = 0, end_ref = 0, end_read = 0, tchunk = CODE_N;
 	int64_t tbase = 0;
-	bool overflow = false, setup = false, qrev = false;
+	bool overflow = false, setup = false, qrev = false, shared_q_built = false;
 	AlignEnds res;
 	res.score_fwd = res.ref_end = res.read_end = res.score_rev = res.ref_begin = res.read_begin = 0;
 
@@ -246,10 +249,11 @@ __global__ void __launch_bounds__(64) k_striped(StripedArgs a)
 				const int row = s * segLen + j;
 				int code = CODE_PAD;                 // pad rows score 0 (sswNew.cpp:195, 690): Q3
 				if (part && row < qlen) code = a.qcodes[qrev ? (qlen - 1 - row) : row];
-				Qs[j] = (uint8_t)(code * 4);
+				if (!SHARED_Q || g == 0 || !shared_q_built) Qs[j] = (uint8_t)(code * 4);
 				Hs[j] = 0;
 				Es[j] = 0;
 			}
+			shared_q_built = true;               // (all groups write identical bytes the first time: benign)
 			ci = 0; maxv = 0; overflow = false;
 			end_ref = WORD ? 0 : -1;                 // sswNew.cpp:278 vs :910
 			end_read = qlen - 1;
@@ -340,13 +344,15 @@ static hipError_t launch_striped_t(const StripedLaunch& L, hipStream_t st)
 	int segLen = (L.max_qlen + P - 1) / P;
 	int s4 = (segLen + 3) & ~3;
 	if (((s4 / 4) & 1) == 0) s4 += 4;          // odd dword stride between stripes: conflict-free LDS rows
-	const size_t gbytes = (size_t)(WORD ? 80 : 48) * s4;
+	constexpr bool SHARED_Q = (MODE == MODE_PRE || MODE == MODE_MAX1);
+	const size_t qbytes = (size_t)16 * s4;
+	const size_t gbytes = (size_t)(SHARED_Q ? (WORD ? 64 : 32) : (WORD ? 80 : 48)) * s4;
 	// up to four 16-lane groups (problems) per one-wave workgroup; long queries get fewer groups so that one group's
 	// H/E/query stripes still fit the 160 KB of LDS
-	int groups = (int)((160 * 1024) / gbytes);
+	int groups = (int)(((size_t)160 * 1024 - (SHARED_Q ? qbytes : 0)) / gbytes);
 	if (groups > 4) groups = 4;
 	if (groups < 1) return hipErrorInvalidValue;           // query too long for the LDS-resident kernel
-	const size_t shmem = (size_t)groups * gbytes;
+	const size_t shmem = (size_t)groups * gbytes + (SHARED_Q ? qbytes : 0);
 	auto kern = k_striped<MODE, WORD, QUIRK>;
 	hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
 	if (err != hipSuccess) return err;
