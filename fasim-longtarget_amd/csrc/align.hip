@@ -94,7 +94,7 @@ __device__ __forceinline__ void lane_rows_a(int v, int seg_len, int vs, int* row
 }
 
 template <int RP>
-__global__ void __launch_bounds__(512) k_align_fwd(FwdArgs a)
+__global__ void __launch_bounds__(256) k_align_fwd(FwdArgs a)
 {
 	__shared__ __align__(16) uint8_t prof[6 * AL_CODE_STRIDE];
 	const int lane = threadIdx.x & 63;
@@ -292,10 +292,10 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st)
 {
 	hipError_t err = hipMemsetAsync(a.counter, 0, sizeof(uint32_t), st);
 	if (err != hipSuccess) return err;
-	// 8 waves share one 43 KB profile: 2 workgroups per CU = 4 waves per SIMD (the VGPR limit)
-	long blocks = ((long)a.ntask + 7) / 8;
-	if (blocks > 256 * 2) blocks = 256 * 2;
-	hipLaunchKernelGGL(k_align_fwd<RP>, dim3((unsigned)blocks), dim3(512), 0, st, a);
+	// 4 waves share one 43 KB profile: 3 workgroups per CU (512-thread workgroups for 4 waves per SIMD measured slower)
+	long blocks = ((long)a.ntask + 3) / 4;
+	if (blocks > 256 * 3) blocks = 256 * 3;
+	hipLaunchKernelGGL(k_align_fwd<RP>, dim3((unsigned)blocks), dim3(256), 0, st, a);
 	return hipGetLastError();
 }
 
