@@ -152,6 +152,17 @@ def main():
     tmax = float(tmax.item())
     total_cells = float(cells.item())
 
+    # untimed extra pass for the kernel-quality figures: ONE batch in flight, so HIP-event durations are those of a
+    # kernel that has the GPU to itself (in the timed steps six batches share it and every duration is stretched)
+    iso = None
+    if rank == 0:
+        eng.set_option("workers", 1)
+        eng.set_option("seg_batch", 1024)
+        nseg_iso = min(1024, mod.segment_count(n, p))
+        iso = eng.scan(None, p, 0, nseg_iso).stats
+        eng.set_option("workers", 0)
+        eng.set_option("seg_batch", 0)
+
     if rank == 0:
         m = len(rna)
         units_per_step = agg["units"] / args.steps
@@ -175,10 +186,12 @@ def main():
         # HBM traffic from the PMC passes (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate
         # rocprofv3 --pmc runs, FETCH doubled per the gfx950 note), scaled to the units one launch of this build processes
         traffic = None
+        traffic_per_unit = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            traffic_per_unit = pmc["k_scan"]["hbm_bytes_per_unit"]
             if dom == 0:
-                traffic = int(pmc["k_scan"]["hbm_bytes_per_unit"] * units_dom / launches)
+                traffic = int(traffic_per_unit * units_dom / launches)
         except Exception:
             traffic = None
         achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9
@@ -218,6 +231,17 @@ def main():
                              "peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (one VALU instruction per lane per clock; the "
                              "packed 16-bit kernels process two cells per lane-instruction); kernel times include "
                              "sharing the GPU with the other batches in flight"},
+        }
+        ik = iso["kernel_ms"]
+        out["isolated_kernels"] = {
+            "what": f"untimed pass over the first {iso['segments']} segments with ONE batch in flight (kernels run alone)",
+            "k_scan": {"ms": round(ik[0], 2), "gcells_per_s": round(iso["cells_stage2"] / (ik[0] * 1e-3) / 1e9, 1),
+                       "valu_frac": round(iso["cells_stage2"] * 5.5 / (ik[0] * 1e-3) / 1e12 / VALU_PEAK_TOPS, 4),
+                       "hbm_GBps": round((traffic_per_unit or 0) * iso["units"] / (ik[0] * 1e-3) / 1e9, 2)},
+            "k_align_fwd": {"ms": round(ik[2], 2), "gcells_per_s": round(iso["align_calls"] and iso["cells_stage3"] / (ik[2] * 1e-3) / 1e9, 1),
+                            "valu_frac": round(iso["cells_stage3"] * 6 / (ik[2] * 1e-3) / 1e12 / VALU_PEAK_TOPS, 4)},
+            "k_striped_hazard_reruns_ms": round(ik[1], 2), "k_finish_lds_ms": round(ik[3], 2),
+            "k_striped_exact_replays_ms": round(ik[5], 2), "k_finish_k_banded_global_ms": round(ik[6], 2),
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(rna_path, m, args.cpu_sample_nt, 12345)

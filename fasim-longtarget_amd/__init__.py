@@ -67,7 +67,7 @@ class _Result(C.Structure):
                 ("stats", ScanStats)]
 
 
-EXPORTS = ["fasim_params_default", "fasim_engine_create", "fasim_engine_destroy", "fasim_last_error", "fasim_set_query",
+EXPORTS = ["fasim_params_default", "fasim_engine_create", "fasim_engine_destroy", "fasim_last_error", "fasim_set_option", "fasim_set_query",
            "fasim_calc_score_once", "fasim_ssw_pre_align", "fasim_pick_candidates", "fasim_ssw_align", "fasim_pre_align_batch",
            "fasim_align_batch", "fasim_encode_unit", "fasim_scan", "fasim_load_dna", "fasim_result_free", "fasim_segment_count",
            "fasim_tfosorted", "fasim_free", "fasim_synth_dna"]
@@ -91,6 +91,7 @@ def lib():
     L.fasim_params_default.argtypes = [C.POINTER(Params)]
     L.fasim_params_default.restype = None
     L.fasim_set_query.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
+    L.fasim_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
     L.fasim_calc_score_once.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(C.c_int32)]
     L.fasim_ssw_pre_align.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(C.c_int32)]
     L.fasim_pick_candidates.argtypes = [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
@@ -226,6 +227,9 @@ class Engine:
     def _check(self, rc):
         if rc != 0:
             raise FasimError(f"libfasim_hip error {rc}: {self._L.fasim_last_error(self._h).decode()}")
+
+    def set_option(self, key: str, value: int):
+        self._check(self._L.fasim_set_option(self._h, key.encode(), value))
 
     def set_query(self, rna: bytes):
         self._check(self._L.fasim_set_query(self._h, rna, len(rna)))

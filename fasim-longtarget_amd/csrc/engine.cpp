@@ -76,6 +76,7 @@ struct fasim_engine {
 	bool align_v1 = false;        // FASIM_ALIGN_V1=1: force the stripe-faithful kernels for stage 3
 	std::vector<fasim_engine*> workers;   // extra engines on the same device: batches in flight concurrently
 	int host_threads_total = 1;
+	int opt_workers = 0, opt_seg_batch = 0;      // fasim_set_option overrides (0 = default / environment)
 	bool query_acgt = true;       // query holds only A,C,G,T: stage-1 and stage-2 scoring coincide on N-free segments
 	bool scan_v1 = false;         // FASIM_SCAN_V1=1: force the stripe-faithful kernels for stages 1 and 2
 	int host_threads = 1;
@@ -770,6 +771,15 @@ void fasim_engine_destroy(fasim_engine* e)
 	delete e;
 }
 
+int fasim_set_option(fasim_engine* E, const char* key, int32_t value)
+{
+	if (!E || !key) return fail(E, FASIM_E_ARG, "null argument");
+	if (!strcmp(key, "workers")) E->opt_workers = value > 0 ? value : 0;
+	else if (!strcmp(key, "seg_batch")) E->opt_seg_batch = value > 0 ? value : 0;
+	else return fail(E, FASIM_E_ARG, "unknown option %s", key);
+	return FASIM_OK;
+}
+
 int fasim_set_query(fasim_engine* E, const char* rna, int32_t len)
 {
 	if (!E) return fail(nullptr, FASIM_E_ARG, "null engine");
@@ -1209,11 +1219,13 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 		int64_t seg_batch = std::max<int64_t>(1, std::min<int64_t>(512, ((int64_t)8 << 30) / ((int64_t)4 * nenc * tstride)));
 		const char* envb = getenv("FASIM_SEG_BATCH");
 		if (envb) seg_batch = std::max(1, atoi(envb));
+		if (E->opt_seg_batch > 0) seg_batch = E->opt_seg_batch;
 		std::vector<std::pair<int64_t, int64_t>> chunks;
 		for (int64_t b0 = seg_first; b0 < seg_first + seg_count; b0 += seg_batch) chunks.push_back({ b0, std::min(seg_first + seg_count, b0 + seg_batch) });
 		int nworkers = 6;
 		const char* envw = getenv("FASIM_WORKERS");
 		if (envw) nworkers = std::max(1, std::min(8, atoi(envw)));
+		if (E->opt_workers > 0) nworkers = std::min(8, E->opt_workers);
 		nworkers = (int)std::min<size_t>((size_t)nworkers, chunks.size());
 		// worker 0 is this engine; the others are lazily created engines on the same device sharing the query
 		while ((int)E->workers.size() < nworkers - 1) {

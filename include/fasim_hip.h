@@ -51,6 +51,10 @@ int  fasim_engine_create(int device, fasim_engine** out);
 void fasim_engine_destroy(fasim_engine* e);
 const char* fasim_last_error(const fasim_engine* e);   /* e may be NULL: last global error */
 
+/* Tuning knobs (optional).  key "workers": batches kept in flight by fasim_scan (default 6, env FASIM_WORKERS);
+ * key "seg_batch": segments per batch (default 512, env FASIM_SEG_BATCH).  value <= 0 restores the default. */
+int fasim_set_option(fasim_engine* e, const char* key, int32_t value);
+
 /* Replaces ssw_init()/init_destroy() (ssw.h:78,83) and init_work() (stats.h:386): the lncRNA is
  * encoded once and stays resident on the device (the reference rebuilds its profile on every call). */
 int fasim_set_query(fasim_engine* e, const char* rna, int32_t len);
