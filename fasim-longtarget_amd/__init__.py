@@ -70,7 +70,7 @@ class _Result(C.Structure):
 EXPORTS = ["fasim_params_default", "fasim_engine_create", "fasim_engine_destroy", "fasim_last_error", "fasim_set_option", "fasim_set_query",
            "fasim_calc_score_once", "fasim_ssw_pre_align", "fasim_pick_candidates", "fasim_ssw_align", "fasim_pre_align_batch",
            "fasim_align_batch", "fasim_encode_unit", "fasim_scan", "fasim_load_dna", "fasim_result_free", "fasim_segment_count",
-           "fasim_tfosorted", "fasim_free", "fasim_synth_dna"]
+           "fasim_tfosorted", "fasim_tfoclass", "fasim_free", "fasim_synth_dna"]
 
 _lib = None
 
@@ -111,6 +111,8 @@ def lib():
     L.fasim_segment_count.restype = C.c_int64
     L.fasim_tfosorted.argtypes = [C.c_void_p, C.c_int64, C.c_char_p, C.c_int64, C.c_char_p, C.c_int64, C.POINTER(Params),
                                   C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    L.fasim_tfoclass.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_char_p, C.c_int64, C.c_int64, C.c_char_p,
+                                 C.POINTER(Params), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
     L.fasim_free.argtypes = [C.c_void_p]
     L.fasim_free.restype = None
     L.fasim_synth_dna.argtypes = [C.c_char_p, C.c_int64, C.c_uint64]
@@ -346,6 +348,24 @@ def tfosorted(result: ScanResult, chr_name: str, start_genome: int, params: Para
                            max(1, len(result.pool)), chr_name.encode(), start_genome, C.byref(p), C.byref(text), C.byref(n))
     if rc != 0:
         raise FasimError(f"fasim_tfosorted failed ({rc}): {L.fasim_last_error(None).decode()}")
+    try:
+        return C.string_at(text, n.value)
+    finally:
+        L.fasim_free(text)
+
+
+def tfoclass(result: ScanResult, level: int, chr_name: str, start_genome: int, dna_len: int, rna_name: str,
+             params: Params | None = None) -> bytes:
+    """-TFOclass<level>-<ds>-<lg> bedGraph bytes (print_cluster, Fasim-LongTarget.cpp:694) for the merged records."""
+    L = lib()
+    p = params or default_params()
+    text = C.c_void_p()
+    n = C.c_int64()
+    recs = C.create_string_buffer(result.recs, len(result.recs)) if result.recs else None
+    rc = L.fasim_tfoclass(C.cast(recs, C.c_void_p) if recs is not None else None, result.count, level, chr_name.encode(),
+                          start_genome, dna_len, rna_name.encode(), C.byref(p), C.byref(text), C.byref(n))
+    if rc != 0:
+        raise FasimError(f"fasim_tfoclass failed ({rc}): {L.fasim_last_error(None).decode()}")
     try:
         return C.string_at(text, n.value)
     finally:

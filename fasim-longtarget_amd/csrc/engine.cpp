@@ -1304,27 +1304,52 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 	return FASIM_OK;
 }
 
-int fasim_tfosorted(const fasim_triplex* recs, int64_t count, const char* pool, int64_t pool_len, const char* chr,
-	int64_t start_genome, const fasim_params* p, char** text, int64_t* text_len)
+static int records_to_list(const fasim_triplex* recs, int64_t count, const char* pool, int64_t pool_len, const fasim_params* p,
+	std::vector<HostTriplex>& list)
 {
-	if ((count > 0 && (!recs || !pool)) || !chr || !p || !text || !text_len || count < 0) return fail(nullptr, FASIM_E_ARG, "bad arguments");
-	std::vector<HostTriplex> list((size_t)count);
+	list.resize((size_t)count);
 	for (int64_t i = 0; i < count; i++) {
 		const fasim_triplex& r = recs[i];
-		if (r.tfo_off < 0 || r.tfo_off >= pool_len || r.tts_off < 0 || r.tts_off >= pool_len) return fail(nullptr, FASIM_E_ARG, "record %lld points outside the pool", (long long)i);
+		if (pool && (r.tfo_off < 0 || r.tfo_off >= pool_len || r.tts_off < 0 || r.tts_off >= pool_len)) return fail(nullptr, FASIM_E_ARG, "record %lld points outside the pool", (long long)i);
 		HostTriplex& t = list[(size_t)i];
 		t.stari = r.stari; t.endi = r.endi; t.starj = r.starj; t.endj = r.endj; t.strand = r.strand; t.reverse = r.reverse;
 		t.rule = r.rule; t.nt = r.nt; t.score = r.score; t.identity = r.identity; t.tri_score = r.tri_score; t.seg = r.seg; t.enc = r.enc;
-		t.tfo = pool + r.tfo_off; t.tts = pool + r.tts_off;
+		t.tfo = pool ? pool + r.tfo_off : ""; t.tts = pool ? pool + r.tts_off : "";
 		if (t.nt > p->cLength && (t.stari + t.endi) / 2 - p->cDistance < 0)
 			return fail(nullptr, FASIM_E_UNSUPPORTED, "a triplex mid-point lies within -ds of the query start: the reference's clustering does not terminate for this input");
 	}
-	std::string s = tfosorted_text(list, chr, (long)start_genome, *p);
+	return FASIM_OK;
+}
+
+static int text_out(const std::string& s, char** text, int64_t* text_len)
+{
 	char* buf = (char*)malloc(s.size() + 1);
 	if (!buf) return fail(nullptr, FASIM_E_NOMEM, "out of memory");
 	memcpy(buf, s.data(), s.size()); buf[s.size()] = 0;
 	*text = buf; *text_len = (int64_t)s.size();
 	return FASIM_OK;
+}
+
+int fasim_tfosorted(const fasim_triplex* recs, int64_t count, const char* pool, int64_t pool_len, const char* chr,
+	int64_t start_genome, const fasim_params* p, char** text, int64_t* text_len)
+{
+	if ((count > 0 && (!recs || !pool)) || !chr || !p || !text || !text_len || count < 0) return fail(nullptr, FASIM_E_ARG, "bad arguments");
+	std::vector<HostTriplex> list;
+	const int rc = records_to_list(recs, count, pool, pool_len, p, list);
+	if (rc != FASIM_OK) return rc;
+	return text_out(tfosorted_text(list, chr, (long)start_genome, *p), text, text_len);
+}
+
+int fasim_tfoclass(const fasim_triplex* recs, int64_t count, int32_t level, const char* chr, int64_t start_genome,
+	int64_t dna_len, const char* rna_name, const fasim_params* p, char** text, int64_t* text_len)
+{
+	if ((count > 0 && !recs) || !chr || !rna_name || !p || !text || !text_len || count < 0 || level < 1 || level > 5)
+		return fail(nullptr, FASIM_E_ARG, "bad arguments");
+	std::vector<HostTriplex> list;
+	const int rc = records_to_list(recs, count, nullptr, 0, p, list);
+	if (rc != FASIM_OK) return rc;
+	cluster_triplex(p->cDistance, p->cLength, list);
+	return text_out(tfoclass_text(list, level, chr, (long)start_genome, (long)dna_len, rna_name, *p), text, text_len);
 }
 
 } // extern "C"

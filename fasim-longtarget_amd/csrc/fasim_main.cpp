@@ -114,7 +114,7 @@ int main(int argc, char* const* argv)
 	std::vector<fasim_triplex> all; std::string pool;
 	// the reference prints ONE file named after the first record (:164-166); later records reuse its chr only
 	// through the per-row chr field, which we keep per record by writing one row block per record.
-	std::string text_all;
+	std::string text_all, text_class[2];
 	for (size_t r = 0; r < recs.size(); r++) {
 		fasim_result* res = nullptr;
 		if (fasim_scan(eng, recs[r].seq.data(), (int64_t)recs[r].seq.size(), 0, -1, &p, &res) != FASIM_OK) { fprintf(stderr, "fasim: %s\n", fasim_last_error(eng)); return 1; }
@@ -130,6 +130,12 @@ int main(int argc, char* const* argv)
 			if (fasim_tfosorted(res->recs, res->count, res->pool, res->pool_len, recs[r].chr.c_str(), recs[r].start, &p, &text, &len) != FASIM_OK) { fprintf(stderr, "fasim: %s\n", fasim_last_error(nullptr)); return 1; }
 			text_all.assign(text, (size_t)len);
 			fasim_free(text);
+			for (int level = 1; level <= 2; level++) {   // print_cluster x2 (:832-836)
+				if (fasim_tfoclass(res->recs, res->count, level, recs[r].chr.c_str(), recs[r].start, (int64_t)recs[r].seq.size(),
+					lnc_name.c_str(), &p, &text, &len) != FASIM_OK) { fprintf(stderr, "fasim: %s\n", fasim_last_error(nullptr)); return 1; }
+				text_class[level - 1].assign(text, (size_t)len);
+				fasim_free(text);
+			}
 		} else {
 			fprintf(stderr, "fasim: multi-record DNA files: only the first record is written (see DESIGN.md, B1)\n");
 			if (r == 0) {
@@ -147,6 +153,12 @@ int main(int argc, char* const* argv)
 	std::ofstream of(path.c_str(), std::ios::trunc);
 	of << text_all;
 	of.close();
+	for (int level = 1; level <= 2 && recs.size() == 1; level++) {   // <prefix>-TFOclass<level>-<ds>-<lg> (:706)
+		const std::string cpath = path.substr(0, path.size() - 10) + "-TFOclass" + std::to_string(level) + "-" +
+			std::to_string(p.cDistance) + "-" + std::to_string(p.cLength);
+		std::ofstream cf(cpath.c_str(), std::ios::trunc);
+		cf << text_class[level - 1];
+	}
 	fasim_engine_destroy(eng);
 	std::cout << "finished normally" << std::endl;
 	return 0;

@@ -332,4 +332,53 @@ std::string tfosorted_text(std::vector<HostTriplex>& list, const std::string& ch
 	return o.str();
 }
 
+// print_cluster() (Fasim-LongTarget.cpp:694-795): bedGraph of the TTS coverage of one class.  The reference walks a
+// std::map with one entry per covered DNA position; here the coverage is swept from interval end points (it scales
+// with the number of triplexes, not with the covered base pairs) and the walk's quirks are applied to whole runs:
+// the first run starts one position early (:751), the last covered position is always a run of its own (:732, :741)
+// and every gap gets a zero line (:760-764).
+std::string tfoclass_text(const std::vector<HostTriplex>& list, int level, const std::string& chr, long start_genome,
+	long dna_size, const std::string& rna_name, const fasim_params& p)
+{
+	const long sg = start_genome - 1;                    // printResult passes start_genome - 1 (:834)
+	std::ostringstream o;
+	o << "browser position " << chr << ":" << sg << "-" << sg + dna_size << std::endl;
+	o << "browser hide all" << std::endl << "browser pack refGene encodeRegions" << std::endl << "browser full altGraph" << std::endl;
+	o << "# 300 base wide bar graph, ausoScale is on by default == graphing" << std::endl;
+	o << "# limits will dynamically change to always show full range of data" << std::endl;
+	o << "# in viewing window, priority = 20 position this as the second graph" << std::endl;
+	o << "# Note, zero-relative, half-open coordinate system in use for bedGraph format" << std::endl;
+	o << "track type=bedGraph name='" << rna_name << " TTS (" << level << ")' description='" << p.cDistance << "-" << p.cLength
+	  << "' visibility=full color=200,100,0 altColor=0,100,200 priority=20" << std::endl;
+
+	std::vector<std::pair<int, int>> ev;                 // (position, +1 / -1), half-open [lo, hi)
+	for (const HostTriplex& t : list) {
+		if (t.motif != level || t.starj == t.endj) continue;
+		ev.push_back({ std::min(t.starj, t.endj), 1 });
+		ev.push_back({ std::max(t.starj, t.endj), -1 });
+	}
+	if (ev.empty()) return o.str();
+	std::sort(ev.begin(), ev.end());
+	struct Run { int a, b, v; };                         // inclusive positions a..b with coverage v > 0
+	std::vector<Run> runs;
+	int depth = 0;
+	for (size_t i = 0; i < ev.size();) {
+		const int pos = ev[i].first;
+		while (i < ev.size() && ev[i].first == pos) depth += ev[i++].second;
+		if (depth <= 0 || i >= ev.size()) continue;
+		if (!runs.empty() && runs.back().b + 1 == pos && runs.back().v == depth) runs.back().b = ev[i].first - 1;   // same level goes on
+		else runs.push_back({ pos, ev[i].first - 1, depth });
+	}
+	const int last = runs.back().b;                      // final_genome - start_genome (:723-726)
+	if (runs.back().a < last) { runs.back().b = last - 1; runs.push_back({ last, last, runs[runs.size() - 1].v }); }
+	const int sgi = (int)sg;
+	for (size_t k = 0; k < runs.size(); k++) {
+		const Run& r = runs[k];
+		if (k + 1 == runs.size()) { o << chr << "\t" << r.a + sgi - 1 << "\t" << r.b + sgi << "\t" << r.v << std::endl; break; }
+		o << chr << "\t" << r.a + sgi - (k == 0 ? 2 : 1) << "\t" << r.b + sgi << "\t" << r.v << std::endl;
+		if (runs[k + 1].a - r.b != 1) o << chr << "\t" << r.b + sgi << "\t" << runs[k + 1].a + sgi - 1 << "\t" << 0 << std::endl;
+	}
+	return o.str();
+}
+
 } // namespace fasim

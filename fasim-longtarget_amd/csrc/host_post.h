@@ -48,5 +48,8 @@ void dedup_top(std::vector<HostTriplex>& mine, const fasim_params& p, std::vecto
 
 void cluster_triplex(int dd, int length, std::vector<HostTriplex>& list);
 std::string tfosorted_text(std::vector<HostTriplex>& list, const std::string& chr, long start_genome, const fasim_params& p);
+// bedGraph of one class (print_cluster); `list` must have been clustered (tfosorted_text or cluster_triplex)
+std::string tfoclass_text(const std::vector<HostTriplex>& list, int level, const std::string& chr, long start_genome,
+	long dna_size, const std::string& rna_name, const fasim_params& p);
 
 } // namespace fasim

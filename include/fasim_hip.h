@@ -137,6 +137,10 @@ int64_t fasim_segment_count(int64_t dna_len, const fasim_params* p);   /* cutSeq
 int fasim_tfosorted(const fasim_triplex* recs, int64_t count, const char* pool, int64_t pool_len,
                     const char* chr, int64_t start_genome, const fasim_params* p,
                     char** text, int64_t* text_len);
+/* print_cluster() (Fasim-LongTarget.cpp:694-795): the bytes of the -TFOclass<level>-<ds>-<lg> bedGraph file for
+ * class `level` (the reference writes levels 1 and 2, :832).  Clusters the records itself; dna_len = record length. */
+int fasim_tfoclass(const fasim_triplex* recs, int64_t count, int32_t level, const char* chr, int64_t start_genome,
+                   int64_t dna_len, const char* rna_name, const fasim_params* p, char** text, int64_t* text_len);
 void fasim_free(void* p);
 
 /* deterministic synthetic DNA (splitmix64, 2 bits/base; same stream as tools/synth.py) */

@@ -773,6 +773,56 @@ std::string tfosorted_text(std::vector<Triplex>& list, const Params& p)
 	return o.str();
 }
 
+// print_cluster() (Fasim-LongTarget.cpp:694-795) for one class level, as text.  `list` must already carry the class of
+// every triplex (cluster_triplex / tfosorted_text ran).  The per-position coverage map of :661-672 is rebuilt here from
+// the records of that class; the run-length walk below keeps the reference's quirks: the first run starts one position
+// early (:751), the LAST covered position is always emitted as a run of its own (:732-736, :741), and a zero-signal
+// line bridges every gap (:760-764).  The stdout chatter of :698 (an uninitialised buffer) is not reproduced.
+std::string tfoclass_text(const std::vector<Triplex>& list, int level, const std::string& chr, long start_genome_m1,
+	long dna_size, const std::string& rna_name, const Params& p)
+{
+	std::map<size_t, size_t> cover;
+	for (const Triplex& t : list) {
+		if (t.motif != level) continue;
+		if (t.endj > t.starj) { for (int j = t.starj; j < t.endj; j++) cover[(size_t)j]++; }
+		else { for (int j = t.endj; j < t.starj; j++) cover[(size_t)j]++; }
+	}
+	std::ostringstream o;
+	const long sg = start_genome_m1;
+	o << "browser position " << chr << ":" << sg << "-" << sg + dna_size << std::endl;
+	o << "browser hide all" << std::endl;
+	o << "browser pack refGene encodeRegions" << std::endl;
+	o << "browser full altGraph" << std::endl;
+	o << "# 300 base wide bar graph, ausoScale is on by default == graphing" << std::endl;
+	o << "# limits will dynamically change to always show full range of data" << std::endl;
+	o << "# in viewing window, priority = 20 position this as the second graph" << std::endl;
+	o << "# Note, zero-relative, half-open coordinate system in use for bedGraph format" << std::endl;
+	o << "track type=bedGraph name='" << rna_name << " TTS (" << level << ")' description='" << p.cDistance << "-" << p.cLength
+	  << "' visibility=full color=200,100,0 altColor=0,100,200 priority=20" << std::endl;
+	if (cover.empty()) return o.str();
+	struct Row { int a, b, v; };
+	std::vector<Row> rows;
+	const int sgi = (int)sg;
+	const int final_genome = (int)(cover.rbegin()->first + sg);
+	bool first_run = true;
+	for (auto it = cover.begin(); it != cover.end();) {
+		const int first0 = (int)it->first;
+		int last = (int)it->first, val = (int)it->second;
+		if ((int)(it->first + sg) == final_genome) { rows.push_back({ first0 + sgi - 1, last + sgi, val }); break; }
+		++it;
+		while (std::labs((long)(it->first - (size_t)last)) == 1 && (int)it->second == val) {
+			if ((int)(it->first + sg) == final_genome) break;
+			last = (int)it->first; val = (int)it->second;
+			++it;
+		}
+		rows.push_back({ first0 + sgi - (first_run ? 2 : 1), last + sgi, val });
+		first_run = false;
+		if (std::labs((long)(it->first - (size_t)last)) != 1) rows.push_back({ last + sgi, (int)it->first + sgi - 1, 0 });
+	}
+	for (const Row& r : rows) o << chr << "\t" << r.a << "\t" << r.b << "\t" << r.v << std::endl;
+	return o.str();
+}
+
 uint64_t fnv1a_ints(const int* v, int n)
 {
 	uint64_t h = 1469598103934665603ULL;

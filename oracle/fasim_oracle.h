@@ -83,6 +83,9 @@ void long_target(const Params& p, const std::string& rna, const std::string& dna
 void assign_genome(std::vector<Triplex>& list, const std::string& chr, long start_genome);
 void cluster_triplex(int dd, int length, std::vector<Triplex>& list);
 std::string tfosorted_text(std::vector<Triplex>& list, const Params& p);   // clusters + sorts `list`
+// bedGraph text of print_cluster() for class `level`; call after tfosorted_text().  start_genome_m1 = start_genome - 1.
+std::string tfoclass_text(const std::vector<Triplex>& list, int level, const std::string& chr, long start_genome_m1,
+	long dna_size, const std::string& rna_name, const Params& p);
 
 uint64_t fnv1a_ints(const int* v, int n);
 bool read_fasta(const char* path, std::string& header, std::string& seq);

@@ -2,6 +2,7 @@
 // CLI around the CPU restatement:
 //   fasim_oracle scan rna.fa dna.fa [opts]       same line protocol as oracle/ref_probe.cpp `scan`
 //   fasim_oracle tfosorted rna.fa dna.fa [opts]   prints the -TFOsorted text to stdout
+//   fasim_oracle tfoclass rna.fa dna.fa -level L [opts]   prints the -TFOclass<L> bedGraph text to stdout
 // Options: -r -t -c -o -i -S -ni -na -pc -pt -ds -lg (as the reference CLI, Fasim-LongTarget.cpp:271-283)
 //          -detail 0|1 -segfirst a -segcount n -threads T
 #include "fasim_oracle.h"
@@ -13,15 +14,15 @@ static uint32_t fbits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
 int main(int argc, char** argv)
 {
-	if (argc < 4 || (strcmp(argv[1], "scan") && strcmp(argv[1], "tfosorted"))) {
-		fprintf(stderr, "usage: fasim_oracle scan|tfosorted rna.fa dna.fa [opts]\n");
+	if (argc < 4 || (strcmp(argv[1], "scan") && strcmp(argv[1], "tfosorted") && strcmp(argv[1], "tfoclass"))) {
+		fprintf(stderr, "usage: fasim_oracle scan|tfosorted|tfoclass rna.fa dna.fa [opts]\n");
 		return 2;
 	}
 	const bool scan = !strcmp(argv[1], "scan");
 	std::string rh, rna, dh, dna;
 	if (!fo::read_fasta(argv[2], rh, rna) || !fo::read_fasta(argv[3], dh, dna)) { fprintf(stderr, "cannot read input\n"); return 2; }
 	fo::Params p;
-	bool detail = true; int segfirst = 0, segcount = 1 << 30, threads = 1;
+	bool detail = true; int segfirst = 0, segcount = 1 << 30, threads = 1, level = 0;
 	for (int i = 4; i + 1 < argc; i += 2) {
 		std::string k = argv[i]; const char* v = argv[i + 1];
 		if (k == "-r") p.rule = atoi(v); else if (k == "-t") p.strand = atoi(v);
@@ -33,6 +34,7 @@ int main(int argc, char** argv)
 		else if (k == "-detail") detail = atoi(v) != 0;
 		else if (k == "-segfirst") segfirst = atoi(v); else if (k == "-segcount") segcount = atoi(v);
 		else if (k == "-threads") threads = atoi(v);
+		else if (k == "-level") level = atoi(v);
 		else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
 	}
 	std::vector<fo::Triplex> list;
@@ -71,6 +73,12 @@ int main(int argc, char** argv)
 	fo::parse_dna_header(dh, species, chr, start);
 	fo::assign_genome(list, chr, start);
 	std::string txt = fo::tfosorted_text(list, p);
+	if (level > 0) {
+		// lncName = the whole RNA header line with every '>' removed, as readRna() keeps it (Fasim-LongTarget.cpp:180-191)
+		std::string name;
+		for (char c : rh) if (c != '>') name += c;
+		txt = fo::tfoclass_text(list, level, chr, start - 1, (long)dna.size(), name, p);
+	}
 	fwrite(txt.data(), 1, txt.size(), stdout);
 	return 0;
 }

@@ -170,6 +170,9 @@ def test_tfosorted_identical(mod, engine, h19, golden_dir, name, dna_name, kw):
     p = mod.default_params(**kw)
     res = engine.scan(dna, p)
     assert mod.tfosorted(res, chro, start, p) == open(os.path.join(golden_dir, name), "rb").read()
+    for level in (1, 2):
+        gold = open(os.path.join(golden_dir, name.replace(".TFOsorted", f".TFOclass{level}")), "rb").read()
+        assert mod.tfoclass(res, level, chro, start, len(dna), "H19", p) == gold
 
 
 def test_rnd30k_tfosorted_and_sharding(mod, engine, h19, golden_dir):
@@ -197,6 +200,9 @@ def test_cli_driver_writes_identical_file(golden_dir, tmp_path):
                    stdout=subprocess.DEVNULL)
     got = (tmp_path / "out" / "hg19-H19-testDNA-TFOsorted").read_bytes()
     assert got == open(os.path.join(golden_dir, "demo_lg40.TFOsorted"), "rb").read()
+    for level in (1, 2):
+        got = (tmp_path / "out" / f"hg19-H19-testDNA-TFOclass{level}-15-40").read_bytes()
+        assert got == open(os.path.join(golden_dir, f"demo_lg40.TFOclass{level}"), "rb").read()
 
 
 def test_live_reference_probe_random_vectors(engine, oracle_build):

@@ -3,6 +3,8 @@ and the pure-host entry points (no device needed) agree with the oracle / the re
 import os
 import re
 
+import pytest
+
 import helpers
 import synth
 import __graft_entry__ as entry
@@ -89,3 +91,30 @@ def test_segment_count():
     for n in (1, 4899, 4900, 4901, 5000, 9800, 9801, 50_000_000):
         starts = list(range(0, n, 4900))
         assert m.segment_count(n) == len(starts)
+
+
+@pytest.mark.parametrize("stem,hdr,n,lg,name", [
+    ("demo_lg40", "hg19|chr11|2158478-2162843", 4366, 40, "H19"),
+    ("demo_default", "hg19|chr11|2158478-2162843", 4366, 50, "H19"),
+    ("planted40k", "syn|chrP|1001-41000", 40000, 40, "H19"),
+    ("q2cat", "syn|chrQ|1-95000", 95000, 40, "H19"),
+    ("malat1", "syn|chrL|1-10000", 10000, 40, None),
+])
+def test_tfoclass_writer_from_reference_rows(golden_dir, stem, hdr, n, lg, name):
+    """Host tail only (no GPU): the rows of a reference -TFOsorted file, fed back through fasim_tfoclass, must give
+    the reference's two bedGraph files byte for byte (print_cluster, Fasim-LongTarget.cpp:694-795)."""
+    mod = _mod()
+    if name is None:
+        name = open(os.path.join(golden_dir, stem.upper() + ".fa")).readline().strip().replace(">", "")
+    rows = open(os.path.join(golden_dir, stem + ".TFOsorted")).read().splitlines()[1:]
+    arr = (mod.Triplex * len(rows))()
+    for t, row in zip(arr, rows):
+        f = row.split("\t")
+        t.stari, t.endi, t.starj, t.endj = int(f[0]), int(f[1]), int(f[2]), int(f[3])
+        t.tri_score, t.identity, t.rule, t.score, t.nt = float(f[8]), float(f[9]), int(f[11]), float(f[12]), int(f[13])
+    res = mod.ScanResult(recs=bytes(arr), pool=b"", stats={})
+    _, chro, start = mod.parse_dna_header(hdr)
+    p = mod.default_params(cLength=lg)
+    for level in (1, 2):
+        got = mod.tfoclass(res, level, chro, start, n, name, p)
+        assert got == open(os.path.join(golden_dir, f"{stem}.TFOclass{level}"), "rb").read()

@@ -30,6 +30,21 @@ def test_demo_tfosorted_identical(oracle_build, golden_dir, name, opts):
     assert out == open(os.path.join(golden_dir, name), "rb").read()
 
 
+@pytest.mark.parametrize("stem,dna_name,opts", [
+    ("demo_lg40", "testDNA.fa", ["-lg", "40"]),
+    ("demo_default", "testDNA.fa", []),
+    ("demo_t1_r3", "testDNA.fa", ["-lg", "30", "-t", "1", "-r", "3"]),
+    ("planted40k", "planted40k.fa", ["-lg", "40"]),
+    ("q2cat", "q2cat.fa", ["-o", "0", "-lg", "40"]),
+])
+def test_tfoclass_bedgraph_identical(oracle_build, golden_dir, stem, dna_name, opts):
+    """print_cluster (Fasim-LongTarget.cpp:694): both bedGraph files the reference CLI wrote next to the -TFOsorted file."""
+    for level in (1, 2):
+        out = helpers.oracle_cli(oracle_build, "tfoclass", os.path.join(golden_dir, "H19.fa"), os.path.join(golden_dir, dna_name),
+                                 "-level", str(level), "-threads", "8", *opts)
+        assert out == open(os.path.join(golden_dir, f"{stem}.TFOclass{level}"), "rb").read()
+
+
 def test_planted40k_scan_and_tfosorted(oracle_build, golden_dir):
     rna, dna = os.path.join(golden_dir, "H19.fa"), os.path.join(golden_dir, "planted40k.fa")
     out = helpers.oracle_cli(oracle_build, "scan", rna, dna, "-threads", "8")
