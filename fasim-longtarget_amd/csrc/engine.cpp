@@ -72,7 +72,7 @@ struct fasim_engine {
 	ScoreLut lut1, lut2;
 	DevBuf q1, q2, enc_lut, counter, dna, seg_start, seg_len, enc_ids, tcodes, colmax, probs, max_out, unit_len,
 		stage1, hits, hits_total, hit_off, hit_cnt, thr, ends, bprobs, bout, scratch, colmax16, unit_ids, flags, stage1_in, hits2,
-		fprobs, ftasks, fstream, fout, aout, cigpool, cigcount, forder, scratch2, boundary, fboundary;
+		fprobs, ftasks, fstream, fout, aout, cigpool, cigcount, forder, scratch2, boundary, fboundary, unit_hz;
 	bool align_v1 = false;        // FASIM_ALIGN_V1=1: force the stripe-faithful kernels for stage 3
 	std::vector<fasim_engine*> workers;   // extra engines on the same device: batches in flight concurrently
 	int host_threads_total = 1;
@@ -261,7 +261,8 @@ int run_scan_v2(fasim_engine* E, const UnitBatch& B, const std::vector<char>& un
 	ScanLaunch L;
 	L.tcodes = E->tcodes.as<uint8_t>(); L.unit_len = E->unit_len.as<int32_t>(); L.tstride = B.tstride;
 	L.counter = E->counter.as<uint32_t>(); L.m = E->m; L.colmax16 = E->colmax16.as<uint16_t>();
-	L.boundary = nullptr;
+	L.boundary = nullptr; L.unit_hz = nullptr;
+	{ const char* c = getenv("FASIM_Q2_COARSE"); L.coarse = (c && atoi(c) > 0) ? 1 : 0; }
 	if (systolic_fits(E->m) && systolic_tiles(E->m) > 1) {
 		HIPOK(E->boundary.ensure((size_t)nu * B.tstride * sizeof(uint2)));
 		L.boundary = E->boundary.as<uint2>();
@@ -283,6 +284,9 @@ int run_scan_v2(fasim_engine* E, const UnitBatch& B, const std::vector<char>& un
 	}
 	rc = upload(E, E->unit_ids, ids.data(), sizeof(int32_t) * nu); if (rc) return rc;
 	L.unit_ids = E->unit_ids.as<int32_t>(); L.nwork = nu; L.qcodes = E->q2.as<uint8_t>(); fill_scores(L.score, false);
+	HIPOK(E->unit_hz.ensure(sizeof(int32_t) * nu));
+	HIPOK(hipMemsetAsync(E->unit_hz.p, 0, sizeof(int32_t) * nu, E->st));
+	L.unit_hz = E->unit_hz.as<int32_t>();
 	{ TimedScope ts(E, 0); he = launch_scan(L, E->st); }
 	if (he == hipErrorInvalidValue) return 1;
 	if (he != hipSuccess) return fail(E, FASIM_E_HIP, "scan launch failed: %s", hipGetErrorString(he));
@@ -297,7 +301,8 @@ int run_scan_v2(fasim_engine* E, const UnitBatch& B, const std::vector<char>& un
 		{ TimedScope ts(E, 4);
 		he = launch_scan_post(E->colmax16.as<uint16_t>(), E->unit_ids.as<int32_t>(), nu, E->unit_len.as<int32_t>(), B.tstride,
 			E->stage1_in.as<int32_t>(), E->hits.as<uint32_t>(), (uint32_t)hits_cap, E->hits_total.as<uint32_t>(),
-			E->hit_off.as<int32_t>(), E->hit_cnt.as<int32_t>(), E->thr.as<int32_t>(), E->stage1.as<int32_t>(), E->flags.as<int32_t>(), E->st); }
+			E->hit_off.as<int32_t>(), E->hit_cnt.as<int32_t>(), E->thr.as<int32_t>(), E->stage1.as<int32_t>(), E->flags.as<int32_t>(),
+			E->unit_hz.as<int32_t>(), E->st); }
 		if (he != hipSuccess) return fail(E, FASIM_E_HIP, "scan_post launch failed: %s", hipGetErrorString(he));
 		uint32_t total = 0;
 		HIPOK(hipMemcpyAsync(&total, E->hits_total.p, sizeof total, hipMemcpyDeviceToHost, E->st));
@@ -314,11 +319,26 @@ int run_scan_v2(fasim_engine* E, const UnitBatch& B, const std::vector<char>& un
 	HIPOK(hipStreamSynchronize(E->st));
 
 	// hazard units: the signed lazy-F exit (Q2) may have fired in the reference -> stripe-faithful re-run
-	std::vector<int> hz;
+	std::vector<int> hz, sat;
 	for (int u = 0; u < nu; u++) {
-		if (out.flags[u] & 4) return fail(E, FASIM_E_OVERFLOW, "score of unit %d left the 16-bit range", u);
+		if (out.flags[u] & 4) sat.push_back(u);
 		if (out.flags[u] & 2) { if (st) st->stage2_overflow_units++; }
-		if (out.flags[u] & 1) hz.push_back(u);
+		if (out.flags[u] & 5) hz.push_back(u);
+	}
+	if (!sat.empty()) {
+		// a score of 16383 or more saturated the doubled 16-bit lanes of k_scan: exact stage-1 score from the 16-bit
+		// stripe-faithful kernel (as calc_score_once's word pass, stats.h:918), column maxima from the hazard path below
+		HIPOK(E->max_out.ensure(sizeof(int32_t) * nu));
+		rc = run_striped(E, MODE_MAX1, true, whole_unit_probs(B, E->m, &sat), true, E->tcodes.as<uint8_t>(), E->m); if (rc) return rc;
+		std::vector<int32_t> all(nu);
+		HIPOK(hipMemcpyAsync(all.data(), E->max_out.p, sizeof(int32_t) * nu, hipMemcpyDeviceToHost, E->st));
+		HIPOK(hipStreamSynchronize(E->st));
+		for (int u : sat) {
+			if (all[u] >= 32767) return fail(E, FASIM_E_OVERFLOW, "stage-1 score of unit %d left the 16-bit range", u);
+			out.stage1[u] = all[u]; out.thr[u] = (int32_t)((double)all[u] * 0.8);
+		}
+		rc = upload(E, E->stage1, out.stage1.data(), sizeof(int32_t) * nu); if (rc) return rc;
+		if (st) st->stage1_word_reruns += (int64_t)sat.size();
 	}
 	if (!hz.empty()) {
 		if (st) st->hazard_units += (int64_t)hz.size();
@@ -351,6 +371,13 @@ int run_scan_v2(fasim_engine* E, const UnitBatch& B, const std::vector<char>& un
 		const size_t base = out.hits.size();
 		out.hits.insert(out.hits.end(), hits2.begin(), hits2.end());
 		for (int u : hz) { out.hit_off[u] = (int32_t)(base + off2[u]); out.hit_cnt[u] = cnt2[u]; }
+	}
+	if (getenv("FASIM_DEBUG_UNITS")) {
+		for (int u = 0; u < nu; u++) {
+			uint64_t h = 1469598103934665603ULL;
+			for (int k = 0; k < out.hit_cnt[u]; k++) { h ^= out.hits[(size_t)out.hit_off[u] + k]; h *= 1099511628211ULL; }
+			fprintf(stderr, "[unit] %d s1=%d thr=%d hits=%d flags=%d h=%016llx\n", u, out.stage1[u], out.thr[u], out.hit_cnt[u], out.flags[u], (unsigned long long)h);
+		}
 	}
 	return FASIM_OK;
 }
@@ -763,7 +790,7 @@ void fasim_engine_destroy(fasim_engine* e)
 	DevBuf* bufs[] = { &e->q1, &e->q2, &e->enc_lut, &e->counter, &e->dna, &e->seg_start, &e->seg_len, &e->enc_ids, &e->tcodes,
 		&e->colmax, &e->probs, &e->max_out, &e->unit_len, &e->stage1, &e->hits, &e->hits_total, &e->hit_off, &e->hit_cnt, &e->thr,
 		&e->ends, &e->bprobs, &e->bout, &e->scratch, &e->dna_res, &e->colmax16, &e->unit_ids, &e->flags, &e->stage1_in, &e->hits2,
-		&e->fprobs, &e->ftasks, &e->fstream, &e->fout, &e->aout, &e->cigpool, &e->cigcount, &e->forder, &e->scratch2, &e->boundary, &e->fboundary };
+		&e->fprobs, &e->ftasks, &e->fstream, &e->fout, &e->aout, &e->cigpool, &e->cigcount, &e->forder, &e->scratch2, &e->boundary, &e->fboundary, &e->unit_hz };
 	for (auto& t : e->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
 	for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
 	for (DevBuf* b : bufs) b->release();

@@ -43,6 +43,8 @@ struct ScanLaunch {
 	const uint8_t* tcodes; const int32_t* unit_ids; const int32_t* unit_len; int32_t nwork; int32_t tstride;
 	uint32_t* counter; const uint8_t* qcodes; int32_t m; int8_t score[25]; uint16_t* colmax16;
 	uint2* boundary;      // [unit][tstride] hand-over rows between query tiles; needed when systolic_tiles(m) > 1
+	int32_t coarse;       // 1: coarse Q2 test (FASIM_Q2_COARSE=1, for measurements)
+	int32_t* unit_hz;     // [unit], zeroed by the caller: |= 1 when the unit needs the stripe-faithful re-run; may be NULL
 };
 int systolic_vs(int m);
 int systolic_tiles(int m);     // query tiles of 128 virtual lanes x <= 24 rows (1 for m <= 3072)
@@ -50,7 +52,7 @@ bool systolic_fits(int m);
 hipError_t launch_scan(const ScanLaunch& L, hipStream_t st);      // hipErrorInvalidValue: query too long for this kernel
 hipError_t launch_scan_post(const uint16_t* colmax16, const int32_t* unit_ids, int32_t nwork, const int32_t* unit_len,
 	int32_t tstride, const int32_t* stage1_in, uint32_t* hits, uint32_t hits_cap, uint32_t* hits_total, int32_t* hit_off,
-	int32_t* hit_cnt, int32_t* thr_out, int32_t* stage1_out, int32_t* flags, hipStream_t st);
+	int32_t* hit_cnt, int32_t* thr_out, int32_t* stage1_out, int32_t* flags, const int32_t* unit_hz, hipStream_t st);
 hipError_t launch_max16(const uint16_t* colmax16, const int32_t* unit_ids, int32_t nwork, const int32_t* unit_len,
 	int32_t tstride, int32_t* out, hipStream_t st);
 

@@ -20,9 +20,17 @@
 // textbook ones up to the reference's overflow column (Q1, applied in k_scan_post) unless the signed
 // lazy-F exit (Q2, sswNew.cpp:369) can trigger.  Q2 needs an F value >= 132 to cross one of the 15 stripe
 // boundaries k*ceil(m/16) of the reference's striped layout.  The rows are laid out so that each of the
-// reference's 16 stripes is exactly 8 virtual lanes: the F entering virtual lane 8k IS the F crossing
-// boundary k, and the kernel raises a per-column hazard bit when it is >= 132.  Hazard units are re-run
-// by the stripe-faithful kernel (kernels.hip).  Zero-score pad rows (Q3) are part of the profile.
+// reference's 16 stripes is exactly `vs` virtual lanes: the F entering virtual lane vs*k IS the F crossing
+// boundary k.  Zero-score pad rows (Q3) are part of the profile.
+//
+// Taint tracking.  Every DP value is carried DOUBLED, with bit 0 = "the reference may hold a smaller value here
+// because of Q2".  Doubled scores and gap costs are even, so the bit rides through add / saturating subtract for
+// free, and max() keeps it exactly when the winning operand carries it (ties go to the tainted operand, which is
+// the safe side).  The hazard test sets the bit on the cells whose value the reference's early lazy-F exit would
+// have withheld; a unit needs the stripe-faithful re-run (kernels.hip) only if a tainted value ends up as a column
+// maximum that matters (above the threshold or at the overflow cut: k_scan_post).  Second-order effects stay on the
+// safe side: the reference's values are never larger than the textbook ones, so a chain that is hot there is hot
+// here; a tainted H counts as "< 144" in the arming test; and a tainted H or F can only produce tainted results.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernels.h"
@@ -38,6 +46,7 @@ __device__ __forceinline__ v2u as_u(v2s x) { return __builtin_bit_cast(v2u, x); 
 __device__ __forceinline__ v2s s_from(int x) { return __builtin_bit_cast(v2s, x); }
 __device__ __forceinline__ int to_int(v2s x) { return __builtin_bit_cast(int, x); }
 __device__ __forceinline__ int to_int(v2u x) { return __builtin_bit_cast(int, x); }
+__device__ __forceinline__ v2u u_fromi(int x) { return __builtin_bit_cast(v2u, x); }
 
 // shift a packed pair down the virtual-lane pipeline: out.lo = x.hi of lane-1 (lane 0: inject), out.hi = x.lo
 __device__ __forceinline__ int vshift(int x, int inject_hi)
@@ -45,6 +54,15 @@ __device__ __forceinline__ int vshift(int x, int inject_hi)
 	const int up = __builtin_amdgcn_update_dpp(inject_hi, x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 	return __builtin_amdgcn_alignbit(x, up, 16);
 }
+
+// Packed 16-bit helpers for the (rare) hazard branch, written as inline asm so that the compiler neither rewrites
+// them into per-half compares/selects nor hoists them into the main path of every step.
+__device__ __forceinline__ v2u pk_subs(v2u a, v2u b) { v2u r; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ v2u pk_subs_k(v2u a, uint32_t k) { v2u r; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "s"(k)); return r; }
+__device__ __forceinline__ v2u pk_ksubs(uint32_t k, v2u a) { v2u r; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "s"(k), "v"(a)); return r; }
+__device__ __forceinline__ v2u pk_minu(v2u a, v2u b) { v2u r; asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ v2u pk_minu_k(v2u a, uint32_t k) { v2u r; asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "s"(k)); return r; }
+__device__ __forceinline__ v2u pk_maxu(v2u a, v2u b) { v2u r; asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 constexpr int SCAN_RS = 24;                 // storage rows per virtual lane in the LDS profile
 constexpr int SCAN_LANE_STRIDE = 112;       // bytes: 2 halves x 24 rows x 2 B + 16 B pad (bank-conflict-free b128)
@@ -63,7 +81,9 @@ struct ScanArgs {
 	int32_t m_pad;               // 16 * ceil(m/16): rows [m, m_pad) score 0 (Q3)
 	int32_t seg_len16;           // ceil(m/16): stripe length of the reference's byte kernels
 	int8_t score[25];            // score[t*5+q]
-	uint16_t* colmax16;          // [unit][tstride] : bit 15 = hazard, bits 0..14 = column maximum
+	uint16_t* colmax16;          // [unit][tstride] : 2 * column maximum + taint bit (32767 = saturated)
+	int32_t* unit_hz;            // [unit] |= 1: the whole unit needs the stripe-faithful re-run (NULL: not tracked)
+	int32_t coarse;              // 1: unit-level test only (any F[b] >= 132), no row analysis
 	int32_t vs;                  // virtual lanes per reference stripe (multiple of 8): 16*vs virtual lanes in all
 	int32_t tile;                // this launch handles virtual lanes [128*tile, 128*tile+128)
 	int32_t ntiles;
@@ -80,7 +100,7 @@ __device__ __forceinline__ void lane_rows(int v, int seg_len, int vs, int* row0,
 }
 
 template <int RP>
-__global__ void __launch_bounds__(256) k_scan(ScanArgs a)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_scan(ScanArgs a)
 {
 	__shared__ __align__(16) uint8_t prof[5 * SCAN_CODE_STRIDE];
 	const int lane = threadIdx.x & 63;
@@ -97,7 +117,7 @@ __global__ void __launch_bounds__(256) k_scan(ScanArgs a)
 		const int row = row0 + r;
 		int sc = SCAN_DEAD;
 		if (r < rows_v) {
-			if (row < a.m) sc = a.score[t * 5 + a.qcodes[row]];
+			if (row < a.m) sc = 2 * a.score[t * 5 + a.qcodes[row]];       // doubled: bit 0 is the taint bit
 			else sc = 0;                      // rows [m, 16*segLen) are the reference's zero-score pad rows (Q3)
 		}
 		*reinterpret_cast<int16_t*>(prof + t * SCAN_CODE_STRIDE + (v >> 1) * SCAN_LANE_STRIDE + (v & 1) * 48 + r * 2) = (int16_t)sc;
@@ -105,15 +125,15 @@ __global__ void __launch_bounds__(256) k_scan(ScanArgs a)
 	__syncthreads();
 
 	// ---- per-lane constants ---------------------------------------------------------------------------
-	// fthr: a half whose virtual lane starts a stripe (v = 8k, k >= 1) sees F[b] of the boundary row b directly as
-	//       its incoming F; Q2 needs F[b] >= 132 (131 = "greater than" threshold), other halves never flag.
+	// fthr: a half whose virtual lane starts a stripe (v = vs*k, k >= 1) sees F[b] of the boundary row b directly as
+	//       its incoming F; Q2 needs F[b] >= 132 (doubled: > 263), other halves never flag.
 	// act : 0xFFFF where the half owns RP rows, 0 where it owns RP-1 (its last register row is transparent)
 	uint32_t fthr = 0xFFFFFFFFu, act = 0, startbits = 0;
 	for (int h = 0; h < 2; h++) {
 		const int v = 128 * a.tile + 2 * lane + h;        // global virtual lane
 		int row0, rows_v;
 		lane_rows(v, a.seg_len16, a.vs, &row0, &rows_v);
-		if (v % a.vs == 0 && v > 0) { fthr = (fthr & ~(0xFFFFu << (16 * h))) | (131u << (16 * h)); startbits |= 0xFFFFu << (16 * h); }
+		if (v % a.vs == 0 && v > 0) { fthr = (fthr & ~(0xFFFFu << (16 * h))) | (263u << (16 * h)); startbits |= 0xFFFFu << (16 * h); }
 		if (rows_v == RP) act |= 0xFFFFu << (16 * h);
 	}
 	const v2u fthr2 = __builtin_bit_cast(v2u, fthr);
@@ -121,7 +141,7 @@ __global__ void __launch_bounds__(256) k_scan(ScanArgs a)
 	// stripe-start halves take the crossing F as the start of a propagation chain
 	const v2u startm = __builtin_bit_cast(v2u, startbits);
 	// the refined test needs F to die inside one stripe (F <= 234 decays by 4 per row)
-	const bool lvl2 = a.seg_len16 >= 96;
+	const bool lvl2 = a.seg_len16 >= 96 && !a.coarse;
 	const uint8_t* pl = prof + lane * SCAN_LANE_STRIDE;
 
 	for (;;) {
@@ -137,11 +157,14 @@ __global__ void __launch_bounds__(256) k_scan(ScanArgs a)
 		const bool first_tile = a.tile == 0, last_tile = a.tile == a.ntiles - 1;
 		uint2 bchunk = make_uint2(0u, 0u);
 
-		v2s H[RP]; v2u E[RP];
+		// H and E are kept as plain 32-bit registers (two packed u16 halves each) and only viewed as vectors inside the
+		// arithmetic: vector-typed loop-carried values get split into halves and re-packed by the compiler
+		int H[RP], E[RP];
 #pragma unroll
-		for (int r = 0; r < RP; r++) { H[r] = (v2s){ 0, 0 }; E[r] = (v2u){ 0, 0 }; }
+		for (int r = 0; r < RP; r++) { H[r] = 0; E[r] = 0; }
 		int tc = 0x00040004;          // target codes of my two halves (N = neutral while the pipeline fills)
 		int hbot = 0, fbot = 0, cm = 0, recv_h_last = 0, fpo = 0;
+		v2u hzacc = (v2u){ 0, 0 };      // != 0: the unit goes to the stripe-faithful kernel (coarse test of short queries)
 		int chunk = CODE_N;
 		const int nsteps = n + 127;
 		for (int step = 0; step < nsteps; step++) {
@@ -166,7 +189,7 @@ __global__ void __launch_bounds__(256) k_scan(ScanArgs a)
 			const int t_lo = tc & 0xff, t_hi = (tc >> 16) & 0xff;
 			const uint8_t* pa = pl + t_lo * SCAN_CODE_STRIDE;
 			const uint8_t* pb = pl + t_hi * SCAN_CODE_STRIDE + 48;
-			v2s hprev = s_from(recv_h_last);          // H[i0-1][c-1]
+			int hprev = recv_h_last;                  // H[i0-1][c-1]
 			recv_h_last = recv_h;
 			v2u f = __builtin_bit_cast(v2u, recv_f);
 			v2s lmax = (v2s){ 0, 0 };
@@ -179,19 +202,19 @@ __global__ void __launch_bounds__(256) k_scan(ScanArgs a)
 					const int r = 8 * g + k;
 					if (r < RP) {
 						const int sc = __builtin_amdgcn_perm(B[k >> 1], A[k >> 1], (k & 1) ? 0x07060302 : 0x05040100);
-						const v2s hold = H[r];
-						v2s h = hprev + s_from(sc);
-						h = __builtin_elementwise_max(h, as_s(E[r]));
+						const int hold = H[r];
+						v2s h = __builtin_elementwise_add_sat(s_from(hprev), s_from(sc));
+						h = __builtin_elementwise_max(h, s_from(E[r]));
 						h = __builtin_elementwise_max(h, as_s(f));
-						H[r] = h;
-						const v2u ho = __builtin_elementwise_sub_sat(as_u(h), (v2u){ GAP_OPEN, GAP_OPEN });
-						E[r] = __builtin_elementwise_max(__builtin_elementwise_sub_sat(E[r], (v2u){ GAP_EXT, GAP_EXT }), ho);
-						const v2u fnew = __builtin_elementwise_max(__builtin_elementwise_sub_sat(f, (v2u){ GAP_EXT, GAP_EXT }), ho);
+						H[r] = to_int(h);
+						const v2u ho = __builtin_elementwise_sub_sat(as_u(h), (v2u){ 2 * GAP_OPEN, 2 * GAP_OPEN });
+						E[r] = to_int(__builtin_elementwise_max(__builtin_elementwise_sub_sat(u_fromi(E[r]), (v2u){ 2 * GAP_EXT, 2 * GAP_EXT }), ho));
+						const v2u fnew = __builtin_elementwise_max(__builtin_elementwise_sub_sat(f, (v2u){ 2 * GAP_EXT, 2 * GAP_EXT }), ho);
 						if (r == RP - 1) {
 							// a half that owns only RP-1 rows passes F and its bottom H through unchanged
 							f = (fnew & actm) | (f & ~actm);
 							lmax = __builtin_elementwise_max(lmax, as_s(as_u(h) & actm));
-							if (RP > 1) hbot = to_int((as_u(h) & actm) | (as_u(H[RP > 1 ? RP - 2 : 0]) & ~actm));
+							if (RP > 1) hbot = (to_int(h) & (int)act) | (H[RP > 1 ? RP - 2 : 0] & ~(int)act);
 							else hbot = to_int(h);
 						} else {
 							f = fnew;
@@ -204,45 +227,58 @@ __global__ void __launch_bounds__(256) k_scan(ScanArgs a)
 			fbot = to_int(f);
 			// ---- Q2 hazard.  The reference's lazy-F loop leaves early (signed compare, sswNew.cpp:369) only while a
 			// stripe's propagated boundary value Fp = F[b] - 4j is >= 132 and the H it has just corrected is < 144
-			// (then vF >= 128 reads as negative, vH < 128 as positive).  fp = F crossing a stripe start, carried down
-			// the rows of the stripe; the row test runs only in the (rare) steps where some lane holds fp >= 132.
-			v2u hz_b = __builtin_elementwise_sub_sat(__builtin_bit_cast(v2u, recv_f), fthr2);     // F[b] >= 132
+			// (then vF >= 128 reads as negative, vH < 128 as positive).  From then on the rows of that stripe whose H is
+			// exactly the propagated value hold something smaller in the reference: those cells get the taint bit.
+			// fp = F crossing a stripe start, carried down the rows of the stripe; the row loop runs only in the (rare)
+			// steps where some lane holds fp >= 132 or an armed chain.  All values are doubled (see the header).
 			fpo = 0;
 			if (lvl2) {
 				// fpo halves: bits 0..14 = propagated value, bit 15 = "an early exit was possible at an earlier row"
 				const v2u fpraw = (__builtin_bit_cast(v2u, recv_f) & startm) | (__builtin_bit_cast(v2u, recv_fp) & ~startm);
 				const v2u fp_in = fpraw & (v2u){ 0x7fff, 0x7fff };
 				const v2u arm_in = (fpraw >> (v2u){ 15, 15 }) & ~startm;
-				const v2u hot = __builtin_elementwise_sub_sat(fp_in, (v2u){ 131, 131 }) | __builtin_elementwise_min(arm_in, fp_in);
-				hz_b = (v2u){ 0, 0 };
+				const v2u hot = pk_subs_k(fp_in, 263u * 0x10001u) | pk_minu(arm_in, fp_in);
 				if (__builtin_amdgcn_ballot_w64(to_int(hot) != 0) != 0ull) {
-					v2u fp = fp_in, arm = arm_in, acc = (v2u){ 0, 0 };
+					v2u fp = fp_in, arm = arm_in;
+					const v2u one = (v2u){ 1, 1 };
+					constexpr uint32_t K1 = 0x00010001u, K263 = 263u * 0x10001u, K288 = 288u * 0x10001u, KE = (2u * GAP_EXT) * 0x10001u,
+						KO = (2u * GAP_OPEN) * 0x10001u;
 #pragma unroll
 					for (int r = 0; r < RP; r++) {
-						const v2u ge = __builtin_elementwise_sub_sat(fp, (v2u){ 131, 131 });                  // Fp >= 132
-						v2u lt = __builtin_elementwise_sub_sat((v2u){ 144, 144 }, as_u(H[r]));               // H < 144
-						// a deviation shows only where, after a possible early exit, H is exactly the propagated value
-						v2u eq = __builtin_elementwise_sub_sat((v2u){ 1, 1 }, __builtin_elementwise_sub_sat(as_u(H[r]), fp));
-						v2u nfp = __builtin_elementwise_sub_sat(fp, (v2u){ GAP_EXT, GAP_EXT });
+						const v2u hr = u_fromi(H[r]);
+						const v2u ge = pk_minu_k(pk_subs_k(fp, K263), K1);                     // Fp >= 132
+						// H < 144; a tainted H may be smaller in the reference, so it counts as "< 144" too
+						v2u lt = pk_minu_k(pk_ksubs(K288, hr), K1) | (hr & one);
+						// the reference keeps a smaller H only where, after a possible early exit, H is exactly the propagated value
+						v2u eq = pk_ksubs(K1, pk_subs(hr, fp));                                // H <= Fp (H >= Fp always)
+						v2u nfp = pk_subs_k(fp, KE);
 						if (r == RP - 1) { lt &= actm; eq &= actm; nfp = (nfp & actm) | (fp & ~actm); }
-						acc = __builtin_elementwise_max(acc, __builtin_elementwise_min(__builtin_elementwise_min(eq, fp), arm));
-						arm = __builtin_elementwise_max(arm, __builtin_elementwise_min(__builtin_elementwise_min(ge, lt), (v2u){ 1, 1 }));
+						const v2u dev = pk_minu(pk_minu(eq, fp), arm);                         // 0 / 1
+						// E of this row was just derived from the untainted H: taint it when it came from H (or ties with it)
+						const v2u ho = pk_subs_k(hr, KO);
+						const v2u efrom = pk_minu(pk_ksubs(K1, pk_subs(u_fromi(E[r]), ho)), ho);
+						H[r] |= to_int(dev);
+						E[r] |= to_int(pk_minu(efrom, dev));
+						arm = pk_maxu(arm, pk_minu(ge, lt));
 						fp = nfp;
 					}
-					hz_b = acc;
+					if (RP > 1) hbot = (H[RP - 1] & (int)act) | (H[RP > 1 ? RP - 2 : 0] & ~(int)act);
+					else hbot = H[0];
 					fpo = to_int(fp | (arm << (v2u){ 15, 15 }));
 				}
+			} else {
+				// short stripes (ceil(m/16) < 96): a chain may cross several stripes, the row analysis does not hold; any
+				// F[b] >= 132 sends the unit to the stripe-faithful kernel
+				hzacc |= __builtin_elementwise_sub_sat(__builtin_bit_cast(v2u, recv_f), fthr2);
 			}
-			const v2u hz = __builtin_elementwise_min(hz_b, (v2u){ 1, 1 }) << (v2u){ 15, 15 };
-			const v2u cin = __builtin_bit_cast(v2u, recv_cm);
-			const v2u cval = __builtin_elementwise_max(cin & (v2u){ 0x7fff, 0x7fff }, as_u(lmax));
-			cm = to_int(cval | ((cin | hz) & (v2u){ 0x8000, 0x8000 }));
+			cm = to_int(__builtin_elementwise_max(__builtin_bit_cast(v2u, recv_cm), as_u(lmax)));
 			const int cdone = step - 127;
 			if (lane == 63 && cdone >= 0) {
 				if (last_tile) out[cdone] = (uint16_t)((uint32_t)cm >> 16);
 				else bnd[cdone] = make_uint2(((uint32_t)hbot >> 16) | ((uint32_t)fbot & 0xffff0000u), ((uint32_t)cm >> 16) | ((uint32_t)fpo & 0xffff0000u));
 			}
 		}
+		if (a.unit_hz && __builtin_amdgcn_ballot_w64(to_int(hzacc) != 0) != 0ull && lane == 0) atomicOr(a.unit_hz + unit, 1);
 	}
 }
 
@@ -272,7 +308,7 @@ hipError_t launch_scan(const ScanLaunch& L, hipStream_t st)
 	a.tcodes = L.tcodes; a.unit_ids = L.unit_ids; a.unit_len = L.unit_len; a.nwork = L.nwork; a.tstride = L.tstride;
 	a.counter = L.counter; a.qcodes = L.qcodes; a.m = L.m; a.m_pad = 16 * ((L.m + 15) / 16); a.seg_len16 = (L.m + 15) / 16;
 	for (int i = 0; i < 25; i++) a.score[i] = L.score[i];
-	a.colmax16 = L.colmax16;
+	a.colmax16 = L.colmax16; a.unit_hz = L.unit_hz; a.coarse = L.coarse;
 	a.vs = systolic_vs(L.m); a.ntiles = a.vs / 8; a.boundary = L.boundary;
 	if (a.ntiles > 1 && !a.boundary) return hipErrorInvalidValue;
 	// RP must be exactly ceil(segLen/vs): every virtual lane then owns RP or RP-1 rows.  One launch per tile of 128
@@ -299,12 +335,13 @@ hipError_t launch_scan(const ScanLaunch& L, hipStream_t st)
 // k_scan_post: one wave per unit.  Applies the reference's overflow rule (Q1, sswNew.cpp:384-395): the first
 // column whose maximum reaches 251 and everything after it is treated as 0; derives the stage-1 score
 // (own maximum unless a separate stage-1 pass supplied it), the threshold (int)(score*0.8), the hazard
-// flag over columns [0, cut], and the ordered list of columns above the threshold.
+// flag (a tainted column maximum that is a hit or decides the cut, or the kernel's own unit flag), and the
+// ordered list of columns above the threshold.  Input values are 2*max + taint.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_scan_post(const uint16_t* __restrict__ colmax16, const int32_t* __restrict__ unit_ids,
 	const int32_t* __restrict__ unit_len, int32_t tstride, const int32_t* __restrict__ stage1_in, uint32_t* __restrict__ hits,
 	uint32_t hits_cap, uint32_t* __restrict__ hits_total, int32_t* __restrict__ hit_off, int32_t* __restrict__ hit_cnt,
-	int32_t* __restrict__ thr_out, int32_t* __restrict__ stage1_out, int32_t* __restrict__ flags)
+	int32_t* __restrict__ thr_out, int32_t* __restrict__ stage1_out, int32_t* __restrict__ flags, const int32_t* __restrict__ unit_hz)
 {
 	const int unit = unit_ids[blockIdx.x];
 	const int lane = threadIdx.x;
@@ -313,7 +350,7 @@ __global__ void __launch_bounds__(64) k_scan_post(const uint16_t* __restrict__ c
 	int mx = 0, cut = n;
 	for (int c0 = 0; c0 < n; c0 += 64) {
 		const int c = c0 + lane;
-		const int v = c < n ? (int)(col[c] & 0x7fff) : 0;
+		const int v = c < n ? (int)(col[c] >> 1) : 0;
 		mx = max(mx, v);
 		const unsigned long long over = __ballot(v >= 255 - BIAS);
 		if (over && cut == n) cut = c0 + __ffsll((long long)over) - 1;
@@ -326,24 +363,24 @@ __global__ void __launch_bounds__(64) k_scan_post(const uint16_t* __restrict__ c
 	for (int c0 = 0; c0 < n; c0 += 64) {
 		const int c = c0 + lane;
 		const int raw = c < n ? (int)col[c] : 0;
-		const int v = raw & 0x7fff;
-		if (c <= cut && (raw & 0x8000)) hz = true;
+		const int v = raw >> 1;
+		if (c <= cut && (raw & 1) && (v > thr || v >= 255 - BIAS)) hz = true;
 		const bool hit = c < cut && v > thr;
 		cnt += __popcll(__ballot(hit));
 	}
-	hz = __ballot(hz) != 0ull;
+	hz = __ballot(hz) != 0ull || (unit_hz && unit_hz[unit] != 0);
 	uint32_t off = 0;
 	if (lane == 0) off = atomicAdd(hits_total, (uint32_t)cnt);
 	off = __shfl(off, 0, 64);
 	if (lane == 0) {
 		hit_off[unit] = (int32_t)off; hit_cnt[unit] = cnt; thr_out[unit] = thr; stage1_out[unit] = s1;
-		flags[unit] = (hz ? 1 : 0) | (cut < n ? 2 : 0) | (mx >= 32000 ? 4 : 0);
+		flags[unit] = (hz ? 1 : 0) | (cut < n ? 2 : 0) | (mx >= 16383 ? 4 : 0);     // 16383 = saturated 16-bit lanes
 	}
 	if ((uint64_t)off + (uint64_t)cnt > hits_cap) return;
 	uint32_t wpos = off;
 	for (int c0 = 0; c0 < n; c0 += 64) {
 		const int c = c0 + lane;
-		const int v = c < n ? (int)(col[c] & 0x7fff) : 0;
+		const int v = c < n ? (int)(col[c] >> 1) : 0;
 		const bool hit = c < cut && v > thr;
 		const unsigned long long b = __ballot(hit);
 		if (hit) hits[wpos + __popcll(b & ((1ull << lane) - 1ull))] = ((uint32_t)c << 8) | (uint32_t)v;
@@ -353,17 +390,17 @@ __global__ void __launch_bounds__(64) k_scan_post(const uint16_t* __restrict__ c
 
 hipError_t launch_scan_post(const uint16_t* colmax16, const int32_t* unit_ids, int32_t nwork, const int32_t* unit_len,
 	int32_t tstride, const int32_t* stage1_in, uint32_t* hits, uint32_t hits_cap, uint32_t* hits_total, int32_t* hit_off,
-	int32_t* hit_cnt, int32_t* thr_out, int32_t* stage1_out, int32_t* flags, hipStream_t st)
+	int32_t* hit_cnt, int32_t* thr_out, int32_t* stage1_out, int32_t* flags, const int32_t* unit_hz, hipStream_t st)
 {
 	if (nwork <= 0) return hipSuccess;
 	hipError_t err = hipMemsetAsync(hits_total, 0, sizeof(uint32_t), st);
 	if (err != hipSuccess) return err;
 	hipLaunchKernelGGL(k_scan_post, dim3((unsigned)nwork), dim3(64), 0, st, colmax16, unit_ids, unit_len, tstride, stage1_in, hits,
-		hits_cap, hits_total, hit_off, hit_cnt, thr_out, stage1_out, flags);
+		hits_cap, hits_total, hit_off, hit_cnt, thr_out, stage1_out, flags, unit_hz);
 	return hipGetLastError();
 }
 
-// maximum of the 15-bit values of each listed unit (used for the separate stage-1 pass of units with N)
+// maximum of the column maxima (stored as 2*max + taint) of each listed unit (used for the separate stage-1 pass of units with N)
 __global__ void __launch_bounds__(64) k_max16(const uint16_t* __restrict__ colmax16, const int32_t* __restrict__ unit_ids,
 	const int32_t* __restrict__ unit_len, int32_t tstride, int32_t* __restrict__ out)
 {
@@ -371,7 +408,7 @@ __global__ void __launch_bounds__(64) k_max16(const uint16_t* __restrict__ colma
 	const int n = unit_len[unit];
 	const uint16_t* col = colmax16 + (int64_t)unit * tstride;
 	int mx = 0;
-	for (int c = threadIdx.x; c < n; c += 64) mx = max(mx, (int)(col[c] & 0x7fff));
+	for (int c = threadIdx.x; c < n; c += 64) mx = max(mx, (int)(col[c] >> 1));
 	for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
 	if (threadIdx.x == 0) out[unit] = mx;
 }
