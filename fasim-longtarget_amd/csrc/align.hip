@@ -34,6 +34,15 @@ __device__ __forceinline__ int a_i(v2u x) { return __builtin_bit_cast(int, x); }
 __device__ __forceinline__ v2u u_from(int x) { return __builtin_bit_cast(v2u, x); }
 __device__ __forceinline__ v2s s_fromi(int x) { return __builtin_bit_cast(v2s, x); }
 
+// packed 16-bit helpers as inline asm for the (rare) hazard branch: keeps the compiler from rewriting them into
+// per-half compares/selects and from hoisting them into every step (see scan.hip)
+__device__ __forceinline__ v2u apk_subs(v2u a, v2u b) { v2u r; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ v2u apk_subs_k(v2u a, uint32_t k) { v2u r; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "s"(k)); return r; }
+__device__ __forceinline__ v2u apk_ksubs(uint32_t k, v2u a) { v2u r; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "s"(k), "v"(a)); return r; }
+__device__ __forceinline__ v2u apk_minu(v2u a, v2u b) { v2u r; asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ v2u apk_minu_k(v2u a, uint32_t k) { v2u r; asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "s"(k)); return r; }
+__device__ __forceinline__ v2u apk_maxu(v2u a, v2u b) { v2u r; asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 __device__ __forceinline__ int vshift2(int x, int inject_hi)
 {
 	const int up = __builtin_amdgcn_update_dpp(inject_hi, x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
@@ -148,9 +157,9 @@ __global__ void __launch_bounds__(256) k_align_fwd(FwdArgs a)
 		const bool first_tile = a.tile == 0, last_tile = a.tile == a.ntiles - 1;
 		uint4 bchunk = make_uint4(0u, 0u, 0u, 0u);
 
-		v2s H[RP]; v2u E[RP];
+		int H[RP], E[RP];                // packed u16 pairs, kept as plain 32-bit registers (see scan.hip)
 #pragma unroll
-		for (int r = 0; r < RP; r++) { H[r] = (v2s){ 0, 0 }; E[r] = (v2u){ 0, 0 }; }
+		for (int r = 0; r < RP; r++) { H[r] = 0; E[r] = 0; }
 		int tc = (CODE_VOID << 16) | CODE_VOID;
 		int hbot = 0, fbot = 0, recv_h_last = 0, fpo = 0;
 		uint32_t klo = 0, khi = 0;           // (colmax << 16) | (0xFFFF - row) of my two virtual lanes' columns
@@ -186,7 +195,7 @@ __global__ void __launch_bounds__(256) k_align_fwd(FwdArgs a)
 			const v2u isvoid = (v2u){ (unsigned short)(t_lo == CODE_VOID ? 0xFFFF : 0), (unsigned short)(t_hi == CODE_VOID ? 0xFFFF : 0) };
 			const v2u dec = isvoid | (v2u){ GAP_EXT * AL_SCALE, GAP_EXT * AL_SCALE };
 			const v2u gapo = isvoid | (v2u){ GAP_OPEN * AL_SCALE, GAP_OPEN * AL_SCALE };
-			v2s hprev = s_fromi(recv_h_last);
+			int hprev = recv_h_last;
 			recv_h_last = recv_h;
 			v2u f = u_from(recv_f);
 			v2s lkey = (v2s){ 0, 0 };
@@ -199,19 +208,19 @@ __global__ void __launch_bounds__(256) k_align_fwd(FwdArgs a)
 					const int r = 8 * g + k;
 					if (r < RP) {
 						const int sc = __builtin_amdgcn_perm(B[k >> 1], A[k >> 1], (k & 1) ? 0x07060302 : 0x05040100);
-						const v2s hold = H[r];
-						v2s h = hprev + s_fromi(sc);
-						h = __builtin_elementwise_max(h, a_s(E[r]));
+						const int hold = H[r];
+						v2s h = s_fromi(hprev) + s_fromi(sc);
+						h = __builtin_elementwise_max(h, s_fromi(E[r]));
 						h = __builtin_elementwise_max(h, a_s(f));
-						H[r] = h;
+						H[r] = a_i(h);
 						const v2u ho = __builtin_elementwise_sub_sat(a_u(h), gapo);
-						E[r] = __builtin_elementwise_max(__builtin_elementwise_sub_sat(E[r], dec), ho);
+						E[r] = a_i(__builtin_elementwise_max(__builtin_elementwise_sub_sat(u_from(E[r]), dec), ho));
 						const v2u fnew = __builtin_elementwise_max(__builtin_elementwise_sub_sat(f, dec), ho);
 						const v2s key = h | (v2s){ (short)(31 - r), (short)(31 - r) };
 						if (r == RP - 1) {
 							f = (fnew & actm) | (f & ~actm);
 							lkey = __builtin_elementwise_max(lkey, a_s(a_u(key) & actm));
-							if (RP > 1) hbot = a_i((a_u(h) & actm) | (a_u(H[RP > 1 ? RP - 2 : 0]) & ~actm));
+							if (RP > 1) hbot = (a_i(h) & (int)act) | (H[RP > 1 ? RP - 2 : 0] & ~(int)act);
 							else hbot = a_i(h);
 						} else {
 							f = fnew;
@@ -230,19 +239,22 @@ __global__ void __launch_bounds__(256) k_align_fwd(FwdArgs a)
 				const v2u fpraw = ((u_from(recv_f) & startm) | (u_from(recv_fp) & ~startm)) & ~isvoid;
 				const v2u fp_in = fpraw & (v2u){ 0x7fff, 0x7fff };
 				const v2u arm_in = (fpraw >> (v2u){ 15, 15 }) & ~startm;
-				const v2u hot = __builtin_elementwise_sub_sat(fp_in, (v2u){ 132 * AL_SCALE - 1, 132 * AL_SCALE - 1 }) | __builtin_elementwise_min(arm_in, fp_in);
+				constexpr uint32_t K1 = 0x00010001u, KGE = (uint32_t)(132 * AL_SCALE - 1) * 0x10001u, KLT = (uint32_t)(144 * AL_SCALE) * 0x10001u,
+					KE = (uint32_t)(GAP_EXT * AL_SCALE) * 0x10001u;
+				const v2u hot = apk_subs_k(fp_in, KGE) | apk_minu(arm_in, fp_in);
 				hz_b = (v2u){ 0, 0 };
 				if (__builtin_amdgcn_ballot_w64(a_i(hot) != 0) != 0ull) {
 					v2u fp = fp_in, arm = arm_in, acc = (v2u){ 0, 0 };
 #pragma unroll
 					for (int r = 0; r < RP; r++) {
-						const v2u ge = __builtin_elementwise_sub_sat(fp, (v2u){ 132 * AL_SCALE - 1, 132 * AL_SCALE - 1 });
-						v2u lt = __builtin_elementwise_sub_sat((v2u){ 144 * AL_SCALE, 144 * AL_SCALE }, a_u(H[r]));
-						v2u eq = __builtin_elementwise_sub_sat((v2u){ 1, 1 }, __builtin_elementwise_sub_sat(a_u(H[r]), fp));
-						v2u nfp = __builtin_elementwise_sub_sat(fp, (v2u){ GAP_EXT * AL_SCALE, GAP_EXT * AL_SCALE });
+						const v2u hr = u_from(H[r]);
+						const v2u ge = apk_subs_k(fp, KGE);
+						v2u lt = apk_ksubs(KLT, hr);
+						v2u eq = apk_ksubs(K1, apk_subs(hr, fp));
+						v2u nfp = apk_subs_k(fp, KE);
 						if (r == RP - 1) { lt &= actm; eq &= actm; nfp = (nfp & actm) | (fp & ~actm); }
-						acc = __builtin_elementwise_max(acc, __builtin_elementwise_min(__builtin_elementwise_min(eq, fp), arm));
-						arm = __builtin_elementwise_max(arm, __builtin_elementwise_min(__builtin_elementwise_min(ge, lt), (v2u){ 1, 1 }));
+						acc = apk_maxu(acc, apk_minu(apk_minu(eq, fp), arm));
+						arm = apk_maxu(arm, apk_minu_k(apk_minu(ge, lt), K1));
 						fp = nfp;
 					}
 					hz_b = acc;
