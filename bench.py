@@ -24,6 +24,8 @@ import sys
 import tempfile
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before anything initialises HIP (see fasim_engine_create)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))

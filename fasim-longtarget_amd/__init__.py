@@ -19,6 +19,10 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+
+# the scan keeps ~10 batches in flight on separate HIP streams; give them more than the runtime's default of four
+# hardware queues (must be in the environment before HIP initialises, i.e. before torch touches the GPU)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 from dataclasses import dataclass
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

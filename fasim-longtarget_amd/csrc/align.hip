@@ -19,6 +19,7 @@
 // stripe-faithful kernel (kernels.hip).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "kernels.h"
 
 namespace fasim {
@@ -305,6 +306,7 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st)
 	hipError_t err = hipMemsetAsync(a.counter, 0, sizeof(uint32_t), st);
 	if (err != hipSuccess) return err;
 	// 4 waves share one 43 KB profile: 3 workgroups per CU (512-thread workgroups for 4 waves per SIMD measured slower)
+	// (the host sizes the tasks so that there are about 3072 of them: one task per wave, workgroups are short-lived)
 	long blocks = ((long)a.ntask + 3) / 4;
 	if (blocks > 256 * 3) blocks = 256 * 3;
 	hipLaunchKernelGGL(k_align_fwd<RP>, dim3((unsigned)blocks), dim3(256), 0, st, a);

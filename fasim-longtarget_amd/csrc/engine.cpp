@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -75,6 +76,13 @@ struct fasim_engine {
 		fprobs, ftasks, fstream, fout, aout, cigpool, cigcount, forder, scratch2, boundary, fboundary, unit_hz;
 	bool align_v1 = false;        // FASIM_ALIGN_V1=1: force the stripe-faithful kernels for stage 3
 	std::vector<fasim_engine*> workers;   // extra engines on the same device: batches in flight concurrently
+	// Gate for the two GPU-filling kernels (k_scan, k_align_fwd).  Without it the workers fall into lock step: all of them
+	// launch a heavy kernel at once, the kernels share the GPU and end together, and then nothing heavy runs while all
+	// workers do their latency-bound tail kernels and host work.  With at most `cap` heavy kernels in flight each one
+	// runs at full speed and the workers stay staggered.
+	struct HeavyGate { std::mutex m; std::condition_variable cv; int in_flight = 0; int cap = 2; };
+	HeavyGate own_gate;
+	HeavyGate* gate = nullptr;            // shared by the workers of one fasim_scan (points at the parent's own_gate)
 	int host_threads_total = 1;
 	int opt_workers = 0, opt_seg_batch = 0;      // fasim_set_option overrides (0 = default / environment)
 	bool query_acgt = true;       // query holds only A,C,G,T: stage-1 and stage-2 scoring coincide on N-free segments
@@ -248,6 +256,25 @@ void fill_scores(int8_t* sc, bool stage1)
 		sc[t * 5 + q] = (int8_t)(stage1 ? ((t == 4 || q == 4) ? -1 : (t == q ? 5 : -4)) : ((t == q && t < 4) ? 5 : -4));
 }
 
+struct GateScope {
+	fasim_engine::HeavyGate* g;
+	explicit GateScope(fasim_engine* E) : g(E->gate)
+	{
+		if (!g) return;
+		std::unique_lock<std::mutex> lk(g->m);
+		g->cv.wait(lk, [&] { return g->in_flight < g->cap; });
+		g->in_flight++;
+	}
+	void release()
+	{
+		if (!g) return;
+		{ std::lock_guard<std::mutex> lk(g->m); g->in_flight--; }
+		g->cv.notify_one();
+		g = nullptr;
+	}
+	~GateScope() { release(); }
+};
+
 // returns 1 when the query does not fit the kernel (caller falls back to the striped kernels)
 int run_scan_v2(fasim_engine* E, const UnitBatch& B, const std::vector<char>& unit_needs_stage1, ScanOut& out,
 	fasim_scan_stats* st)
@@ -287,9 +314,13 @@ int run_scan_v2(fasim_engine* E, const UnitBatch& B, const std::vector<char>& un
 	HIPOK(E->unit_hz.ensure(sizeof(int32_t) * nu));
 	HIPOK(hipMemsetAsync(E->unit_hz.p, 0, sizeof(int32_t) * nu, E->st));
 	L.unit_hz = E->unit_hz.as<int32_t>();
-	{ TimedScope ts(E, 0); he = launch_scan(L, E->st); }
-	if (he == hipErrorInvalidValue) return 1;
-	if (he != hipSuccess) return fail(E, FASIM_E_HIP, "scan launch failed: %s", hipGetErrorString(he));
+	{
+		GateScope gate(E);
+		{ TimedScope ts(E, 0); he = launch_scan(L, E->st); }
+		if (he == hipErrorInvalidValue) return 1;
+		if (he != hipSuccess) return fail(E, FASIM_E_HIP, "scan launch failed: %s", hipGetErrorString(he));
+		HIPOK(hipStreamSynchronize(E->st));
+	}
 
 	HIPOK(E->hit_off.ensure(sizeof(int32_t) * nu)); HIPOK(E->hit_cnt.ensure(sizeof(int32_t) * nu));
 	HIPOK(E->thr.ensure(sizeof(int32_t) * nu)); HIPOK(E->hits_total.ensure(64));
@@ -559,6 +590,7 @@ int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& 
 	g_prof.add(1, "run_fwd upload", now_s() - tp);
 	HIPOK(E->fstream.ensure((size_t)off + 256));
 	HIPOK(E->fout.ensure(sizeof(FwdOut) * n));
+	GateScope gate(E);
 	hipError_t he = launch_build_stream(E->tcodes.as<uint8_t>(), E->fprobs.as<FwdProb>(), n, E->fstream.as<uint8_t>(), E->st);
 	if (he != hipSuccess) return fail(E, FASIM_E_HIP, "build_stream launch failed: %s", hipGetErrorString(he));
 	FwdLaunch L;
@@ -571,6 +603,7 @@ int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& 
 	if (he != hipSuccess) return fail(E, FASIM_E_HIP, "align_fwd launch failed: %s", hipGetErrorString(he));
 	tp = now_s();
 	HIPOK(hipStreamSynchronize(E->st));
+	gate.release();
 	g_prof.add(2, "run_fwd kernel wait", now_s() - tp);
 	tp = now_s();
 	HIPOK(hipMemcpyAsync(fo.data(), E->fout.p, sizeof(FwdOut) * n, hipMemcpyDeviceToHost, E->st));
@@ -756,6 +789,10 @@ int fasim_engine_create(int device, fasim_engine** out)
 {
 	if (!out) return fail(nullptr, FASIM_E_ARG, "null out pointer");
 	*out = nullptr;
+	// fasim_scan keeps ~10 batches in flight on as many streams; the HIP runtime multiplexes streams onto 4 hardware
+	// queues unless told otherwise, which serialises unrelated batches.  Only effective before the runtime initialises
+	// (a host application that touches HIP earlier should export GPU_MAX_HW_QUEUES itself).
+	setenv("GPU_MAX_HW_QUEUES", "8", 0);
 	int count = 0;
 	hipError_t he = hipGetDeviceCount(&count);
 	if (he != hipSuccess || count <= 0) return fail(nullptr, FASIM_E_NODEVICE, "no HIP device available (%s); this library has no CPU fallback", hipGetErrorString(he));
@@ -1247,12 +1284,17 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 		const char* envb = getenv("FASIM_SEG_BATCH");
 		if (envb) seg_batch = std::max(1, atoi(envb));
 		if (E->opt_seg_batch > 0) seg_batch = E->opt_seg_batch;
-		std::vector<std::pair<int64_t, int64_t>> chunks;
-		for (int64_t b0 = seg_first; b0 < seg_first + seg_count; b0 += seg_batch) chunks.push_back({ b0, std::min(seg_first + seg_count, b0 + seg_batch) });
-		int nworkers = 6;
+		int nworkers = 10;
 		const char* envw = getenv("FASIM_WORKERS");
-		if (envw) nworkers = std::max(1, std::min(8, atoi(envw)));
-		if (E->opt_workers > 0) nworkers = std::min(8, E->opt_workers);
+		if (envw) nworkers = std::max(1, std::min(16, atoi(envw)));
+		if (E->opt_workers > 0) nworkers = std::min(16, E->opt_workers);
+		// chunks of at most seg_batch segments; their number is rounded up to a multiple of the worker count so that all
+		// workers finish together (a step of 20 batches on 12 workers would otherwise end with 8 of them idle)
+		int64_t nchunks = (seg_count + seg_batch - 1) / seg_batch;
+		if (nchunks > nworkers) nchunks = (nchunks + nworkers - 1) / nworkers * nworkers;
+		const int64_t per_chunk_segs = (seg_count + nchunks - 1) / std::max<int64_t>(1, nchunks);
+		std::vector<std::pair<int64_t, int64_t>> chunks;
+		for (int64_t b0 = seg_first; b0 < seg_first + seg_count; b0 += per_chunk_segs) chunks.push_back({ b0, std::min(seg_first + seg_count, b0 + per_chunk_segs) });
 		nworkers = (int)std::min<size_t>((size_t)nworkers, chunks.size());
 		// worker 0 is this engine; the others are lazily created engines on the same device sharing the query
 		while ((int)E->workers.size() < nworkers - 1) {
@@ -1262,7 +1304,12 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 		}
 		std::vector<fasim_engine*> ws(1, E);
 		for (int k = 0; k < nworkers - 1; k++) ws.push_back(E->workers[k]);
+		{
+			const char* envg = getenv("FASIM_HEAVY_GATE");      // heavy kernels in flight at once (0 = no gate)
+			E->own_gate.cap = envg ? atoi(envg) : 2;
+		}
 		for (fasim_engine* w : ws) {
+			w->gate = (ws.size() > 1 && E->own_gate.cap > 0) ? &E->own_gate : nullptr;
 			if (w != E && (w->rna != E->rna)) { rc = fasim_set_query(w, E->rna.data(), E->m); if (rc) return fail(E, rc, "worker set_query failed: %s", fasim_last_error(w)); }
 			w->scan_v1 = E->scan_v1; w->align_v1 = E->align_v1;
 			w->host_threads = std::max(1, E->host_threads_total / nworkers);

@@ -33,6 +33,7 @@
 // here; a tainted H counts as "< 144" in the arming test; and a tainted H or F can only produce tainted results.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "kernels.h"
 
 namespace fasim {
@@ -288,8 +289,13 @@ static hipError_t launch_scan_t(const ScanArgs& a, hipStream_t st)
 	hipError_t err = hipMemsetAsync(a.counter, 0, sizeof(uint32_t), st);
 	if (err != hipSuccess) return err;
 	long waves = a.nwork;
+	// Short-lived workgroups (each wave takes about `per_wave` units from the queue) instead of a persistent grid: slots
+	// free up every few milliseconds, so the latency-bound kernels of the other batches in flight get dispatched at once
+	// instead of waiting for this kernel to drain.  FASIM_GRID_UNITS=0 restores the persistent grid.
+	static const int per_wave = [] { const char* e = getenv("FASIM_GRID_UNITS"); return e ? atoi(e) : 2; }();
 	long blocks = (waves + 3) / 4;
-	if (blocks > 256 * 4) blocks = 256 * 4;
+	if (per_wave > 0) blocks = (waves + 4 * per_wave - 1) / (4 * per_wave);
+	else if (blocks > 256 * 4) blocks = 256 * 4;
 	hipLaunchKernelGGL(k_scan<RP>, dim3((unsigned)blocks), dim3(256), 0, st, a);
 	return hipGetLastError();
 }
