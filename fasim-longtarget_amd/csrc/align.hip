@@ -7,7 +7,11 @@
 //                   (score -inf, gap registers = 0xFFFF so that the saturating subtractions clear E and F)
 //                   reset the DP state in flight.  DP values are kept scaled by 32 so that the low 5 bits of
 //                   every H can carry (31 - row-in-lane): one v_pk_max then yields, per column, the maximum
-//                   AND the smallest row that holds it (read_end, sswNew.cpp:621-629).
+//                   AND the smallest row that holds it (read_end, sswNew.cpp:621-629).  The TAINT variant (first,
+//                   8-bit-semantics pass) scales by 64 and uses bit 5 as the Q2 taint bit of scan.hip: a window
+//                   needs the stripe-faithful replay only if the cell that WINS (first column of the maximum,
+//                   smallest row) is tainted -- every other cell only has to be "not larger", which the
+//                   reference's smaller values cannot break.
 //   k_finish        per alignment (one thread): the reverse pass (sswNew.cpp:1508-1520) and banded_sw
 //                   (sswNew.cpp:1071-1259).  Every alignment of the winning score inside the reverse
 //                   rectangle ends in its corner (ref_end is the FIRST column reaching the score, read_end
@@ -103,9 +107,10 @@ __device__ __forceinline__ void lane_rows_a(int v, int seg_len, int vs, int* row
 	*row0 = s * seg_len + j * q + (j < rem ? j : rem);
 }
 
-template <int RP>
+template <int RP, bool TAINT>
 __global__ void __launch_bounds__(256) k_align_fwd(FwdArgs a)
 {
+	constexpr int SC = TAINT ? 2 * AL_SCALE : AL_SCALE;      // value scale; TAINT: bit 5 = taint, bits 0..4 = row tag
 	__shared__ __align__(16) uint8_t prof[6 * AL_CODE_STRIDE];
 	const int lane = threadIdx.x & 63;
 
@@ -118,7 +123,7 @@ __global__ void __launch_bounds__(256) k_align_fwd(FwdArgs a)
 		const int row = row0v + r;
 		int sc = AL_NEG;
 		if (t < 5 && r < rows_v) {
-			if (row < a.m) { const int q = a.qcodes[row]; sc = ((q == t && t < 4) ? 5 : -4) * AL_SCALE; }
+			if (row < a.m) { const int q = a.qcodes[row]; sc = ((q == t && t < 4) ? 5 : -4) * SC; }
 			else sc = 0;
 		}
 		*reinterpret_cast<int16_t*>(prof + t * AL_CODE_STRIDE + (v >> 1) * AL_LANE_STRIDE + (v & 1) * 48 + r * 2) = (int16_t)sc;
@@ -132,13 +137,13 @@ __global__ void __launch_bounds__(256) k_align_fwd(FwdArgs a)
 		const int v = 128 * a.tile + 2 * lane + h;
 		int rows_v;
 		lane_rows_a(v, a.seg_len16, a.vs, &row0[h], &rows_v);
-		if (v % a.vs == 0 && v > 0) { fthr = (fthr & ~(0xFFFFu << (16 * h))) | ((131u * AL_SCALE + (AL_SCALE - 1)) << (16 * h)); startbits |= 0xFFFFu << (16 * h); }
+		if (v % a.vs == 0 && v > 0) { fthr = (fthr & ~(0xFFFFu << (16 * h))) | ((131u * SC + (SC - 1)) << (16 * h)); startbits |= 0xFFFFu << (16 * h); }
 		if (rows_v == RP) act |= 0xFFFFu << (16 * h);
 	}
 	const v2u fthr2 = u_from((int)fthr);
 	const v2u actm = u_from((int)act);
 	const v2u startm = u_from((int)startbits);
-	const bool lvl2 = a.seg_len16 >= 96;
+	const bool lvl2 = a.seg_len16 >= 96;      // (the 16-bit pass, !TAINT, needs no Q2 test at all: its compare is unaffected)
 	const uint8_t* pl = prof + lane * AL_LANE_STRIDE;
 	// (31 - r) tags for the row keys, and the base of the global-row key of my two virtual lanes
 	const int kbase_lo = 0xFFFF - row0[0] - 31, kbase_hi = 0xFFFF - row0[1] - 31;
@@ -166,7 +171,7 @@ __global__ void __launch_bounds__(256) k_align_fwd(FwdArgs a)
 		uint32_t klo = 0, khi = 0;           // (colmax << 16) | (0xFFFF - row) of my two virtual lanes' columns
 		int chunk = CODE_VOID;
 		// pipe-end state (meaningful in lane 63)
-		int pidx = p0, cidx = 0, runmax = 0, end_ref = -1, end_read = 0, hzflag = 0, over = 0;
+		int pidx = p0, cidx = 0, runmax = 0, end_ref = -1, end_read = 0, hzflag = 0, over = 0, wtaint = 0;
 		const int nsteps = slen + 127;
 		for (int step = 0; step < nsteps; step++) {
 			if ((step & 63) == 0) {
@@ -194,8 +199,8 @@ __global__ void __launch_bounds__(256) k_align_fwd(FwdArgs a)
 			const uint8_t* pb = pl + t_hi * AL_CODE_STRIDE + 48;
 			// void columns clear E and F: the saturating subtractions use 0xFFFF instead of 4*32 / 16*32
 			const v2u isvoid = (v2u){ (unsigned short)(t_lo == CODE_VOID ? 0xFFFF : 0), (unsigned short)(t_hi == CODE_VOID ? 0xFFFF : 0) };
-			const v2u dec = isvoid | (v2u){ GAP_EXT * AL_SCALE, GAP_EXT * AL_SCALE };
-			const v2u gapo = isvoid | (v2u){ GAP_OPEN * AL_SCALE, GAP_OPEN * AL_SCALE };
+			const v2u dec = isvoid | (v2u){ GAP_EXT * SC, GAP_EXT * SC };
+			const v2u gapo = isvoid | (v2u){ GAP_OPEN * SC, GAP_OPEN * SC };
 			int hprev = recv_h_last;
 			recv_h_last = recv_h;
 			v2u f = u_from(recv_f);
@@ -210,7 +215,7 @@ __global__ void __launch_bounds__(256) k_align_fwd(FwdArgs a)
 					if (r < RP) {
 						const int sc = __builtin_amdgcn_perm(B[k >> 1], A[k >> 1], (k & 1) ? 0x07060302 : 0x05040100);
 						const int hold = H[r];
-						v2s h = s_fromi(hprev) + s_fromi(sc);
+						v2s h = TAINT ? __builtin_elementwise_add_sat(s_fromi(hprev), s_fromi(sc)) : s_fromi(hprev) + s_fromi(sc);
 						h = __builtin_elementwise_max(h, s_fromi(E[r]));
 						h = __builtin_elementwise_max(h, a_s(f));
 						H[r] = a_i(h);
@@ -232,38 +237,45 @@ __global__ void __launch_bounds__(256) k_align_fwd(FwdArgs a)
 				}
 			}
 			fbot = a_i(f);
-			// hazard (possible Q2): the F entering a stripe-starting virtual lane is >= 132
-			// (same refined Q2 test as scan.hip, on values scaled by 32; void columns carry no F)
-			v2u hz_b = __builtin_elementwise_sub_sat(u_from(recv_f), fthr2);
+			// Q2 (8-bit pass only).  Short queries: any F[b] >= 132 entering a stripe flags the column (TAG_HZ).  Otherwise the
+			// row analysis of scan.hip marks the cells the reference's early lazy-F exit would have left smaller (taint bit).
 			fpo = 0;
-			if (lvl2) {
-				const v2u fpraw = ((u_from(recv_f) & startm) | (u_from(recv_fp) & ~startm)) & ~isvoid;
-				const v2u fp_in = fpraw & (v2u){ 0x7fff, 0x7fff };
-				const v2u arm_in = (fpraw >> (v2u){ 15, 15 }) & ~startm;
-				constexpr uint32_t K1 = 0x00010001u, KGE = (uint32_t)(132 * AL_SCALE - 1) * 0x10001u, KLT = (uint32_t)(144 * AL_SCALE) * 0x10001u,
-					KE = (uint32_t)(GAP_EXT * AL_SCALE) * 0x10001u;
-				const v2u hot = apk_subs_k(fp_in, KGE) | apk_minu(arm_in, fp_in);
-				hz_b = (v2u){ 0, 0 };
-				if (__builtin_amdgcn_ballot_w64(a_i(hot) != 0) != 0ull) {
-					v2u fp = fp_in, arm = arm_in, acc = (v2u){ 0, 0 };
+			if (TAINT) {
+				if (lvl2) {
+					const v2u fpraw = ((u_from(recv_f) & startm) | (u_from(recv_fp) & ~startm)) & ~isvoid;
+					const v2u fp_in = fpraw & (v2u){ 0x7fff, 0x7fff };
+					const v2u arm_in = (fpraw >> (v2u){ 15, 15 }) & ~startm;
+					constexpr uint32_t K1 = 0x00010001u, KGE = (uint32_t)(132 * SC - 1) * 0x10001u, KLT = (uint32_t)(144 * SC) * 0x10001u,
+						KE = (uint32_t)(GAP_EXT * SC) * 0x10001u, KO = (uint32_t)(GAP_OPEN * SC) * 0x10001u;
+					const v2u hot = apk_subs_k(fp_in, KGE) | apk_minu(arm_in, fp_in);
+					if (__builtin_amdgcn_ballot_w64(a_i(hot) != 0) != 0ull) {
+						v2u fp = fp_in, arm = arm_in;
+						const v2u one = (v2u){ 1, 1 };
 #pragma unroll
-					for (int r = 0; r < RP; r++) {
-						const v2u hr = u_from(H[r]);
-						const v2u ge = apk_subs_k(fp, KGE);
-						v2u lt = apk_ksubs(KLT, hr);
-						v2u eq = apk_ksubs(K1, apk_subs(hr, fp));
-						v2u nfp = apk_subs_k(fp, KE);
-						if (r == RP - 1) { lt &= actm; eq &= actm; nfp = (nfp & actm) | (fp & ~actm); }
-						acc = apk_maxu(acc, apk_minu(apk_minu(eq, fp), arm));
-						arm = apk_maxu(arm, apk_minu_k(apk_minu(ge, lt), K1));
-						fp = nfp;
+						for (int r = 0; r < RP; r++) {
+							const v2u hr = u_from(H[r]);
+							const v2u ge = apk_minu_k(apk_subs_k(fp, KGE), K1);                         // Fp >= 132
+							v2u lt = apk_minu_k(apk_ksubs(KLT, hr), K1) | ((hr >> (v2u){ 5, 5 }) & one);      // H < 144, or tainted
+							v2u eq = apk_ksubs(K1, apk_subs(hr, fp));                                   // H == Fp (H >= Fp always)
+							v2u nfp = apk_subs_k(fp, KE);
+							if (r == RP - 1) { lt &= actm; eq &= actm; nfp = (nfp & actm) | (fp & ~actm); }
+							const v2u dev = apk_minu(apk_minu(eq, fp), arm);                            // 0 / 1
+							const v2u ho = apk_subs_k(hr, KO);
+							const v2u efrom = apk_minu(apk_ksubs(K1, apk_subs(u_from(E[r]), ho)), ho);
+							H[r] |= a_i(dev << (v2u){ 5, 5 });
+							E[r] |= a_i(apk_minu(efrom, dev) << (v2u){ 5, 5 });
+							arm = apk_maxu(arm, apk_minu(ge, lt));
+							fp = nfp;
+						}
+						if (RP > 1) hbot = (H[RP - 1] & (int)act) | (H[RP > 1 ? RP - 2 : 0] & ~(int)act);
+						else hbot = H[0];
+						fpo = a_i(fp | (arm << (v2u){ 15, 15 }));
 					}
-					hz_b = acc;
-					fpo = a_i(fp | (arm << (v2u){ 15, 15 }));
+				} else {
+					const v2u hz_b = __builtin_elementwise_sub_sat(u_from(recv_f), fthr2);
+					tc |= a_i(__builtin_elementwise_min(hz_b, (v2u){ 1, 1 }) << (v2u){ 4, 4 });
 				}
 			}
-			const v2u hzb = __builtin_elementwise_min(hz_b, (v2u){ 1, 1 }) << (v2u){ 4, 4 };
-			tc |= a_i(hzb);
 			// per-column (max, smallest row) keys
 			const uint32_t lk = (uint32_t)a_i(lkey);
 			const uint32_t loc_lo = (((lk & 0xFFFFu) >> 5) << 16) | (uint32_t)(kbase_lo + (int)(lk & 31u));
@@ -282,17 +294,23 @@ __global__ void __launch_bounds__(256) k_align_fwd(FwdArgs a)
 			if (lane == 63 && last_tile) {
 				const int tag = (tc >> 16) & 0xff;
 				if ((tag & 7) != CODE_VOID) {
-					const int colmax = (int)(khi >> 16);
-					if (!over && (tag & TAG_HZ)) hzflag = 1;
-					if (colmax > runmax) { runmax = colmax; end_ref = cidx; end_read = 0xFFFF - (int)(khi & 0xFFFFu); }
-					if (runmax >= 255 - BIAS) over = 1;
+					// TAINT: the key's value field is 2 * maximum + taint of the winning cell
+					const int cfield = (int)(khi >> 16);
+					const int colmax = TAINT ? (cfield >> 1) : cfield;
+					// 8-bit pass: the reference stops at the first column whose maximum reaches 251 (overflow -> 16-bit pass), so
+					// nothing after that column matters (in particular not the saturated, hence "tainted", values further on)
+					if (!(TAINT && over)) {
+						if (tag & TAG_HZ) hzflag = 1;
+						if (colmax > runmax) { runmax = colmax; end_ref = cidx; end_read = 0xFFFF - (int)(khi & 0xFFFFu); wtaint = TAINT ? (cfield & 1) : 0; }
+						if (runmax >= 255 - BIAS) over = 1;
+					}
 					cidx++;
 					if (tag & TAG_LAST) {
 						FwdOut o;
 						o.score = runmax; o.ref_end = end_ref; o.read_end = end_read < a.m - 1 ? end_read : a.m - 1;
-						o.flags = hzflag; o.ref_begin = 0; o.read_begin = 0;
+						o.flags = hzflag | wtaint; o.ref_begin = 0; o.read_begin = 0;
 						a.out[pidx] = o;
-						pidx++; cidx = 0; runmax = 0; end_ref = -1; end_read = 0; hzflag = 0; over = 0;
+						pidx++; cidx = 0; runmax = 0; end_ref = -1; end_read = 0; hzflag = 0; over = 0; wtaint = 0;
 					}
 				}
 			}
@@ -300,7 +318,7 @@ __global__ void __launch_bounds__(256) k_align_fwd(FwdArgs a)
 	}
 }
 
-template <int RP>
+template <int RP, bool TAINT>
 static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st)
 {
 	hipError_t err = hipMemsetAsync(a.counter, 0, sizeof(uint32_t), st);
@@ -309,7 +327,7 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st)
 	// (the host sizes the tasks so that there are about 3072 of them: one task per wave, workgroups are short-lived)
 	long blocks = ((long)a.ntask + 3) / 4;
 	if (blocks > 256 * 3) blocks = 256 * 3;
-	hipLaunchKernelGGL(k_align_fwd<RP>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+	hipLaunchKernelGGL((k_align_fwd<RP, TAINT>), dim3((unsigned)blocks), dim3(256), 0, st, a);
 	return hipGetLastError();
 }
 
@@ -327,7 +345,7 @@ hipError_t launch_align_fwd(const FwdLaunch& L, hipStream_t st)
 		a.tile = t;
 		hipError_t err = hipErrorInvalidValue;
 		switch (rp) {
-#define FASIM_FWD_CASE(N) case N: err = launch_fwd_t<N>(a, st); break;
+#define FASIM_FWD_CASE(N) case N: err = L.word ? launch_fwd_t<N, false>(a, st) : launch_fwd_t<N, true>(a, st); break;
 		FASIM_FWD_CASE(1) FASIM_FWD_CASE(2) FASIM_FWD_CASE(3) FASIM_FWD_CASE(4) FASIM_FWD_CASE(5) FASIM_FWD_CASE(6)
 		FASIM_FWD_CASE(7) FASIM_FWD_CASE(8) FASIM_FWD_CASE(9) FASIM_FWD_CASE(10) FASIM_FWD_CASE(11) FASIM_FWD_CASE(12)
 		FASIM_FWD_CASE(13) FASIM_FWD_CASE(14) FASIM_FWD_CASE(15) FASIM_FWD_CASE(16) FASIM_FWD_CASE(17) FASIM_FWD_CASE(18)
@@ -429,54 +447,67 @@ __global__ void __launch_bounds__(64) k_finish(const uint8_t* __restrict__ tcode
 	const uint8_t* ref = tw + ref_begin;
 	const uint8_t* read = qcodes + read_begin;
 	const int refLen = fo.ref_end - ref_begin + 1, readLen = fo.read_end - read_begin + 1, score = fo.score;
-	int wmax = scratch_cap / 64;
-	if (wmax > 4099) wmax = 4099;
-	if (wmax < 8) wmax = 8;
+	// The reference keeps three band arrays of 2*band+3 ints and 3 direction bytes per band cell, width_d = 2*band+1 per
+	// row.  Only columns [max(0,i-band), min(refLen-1,i+band)] of row i exist, so array indices never exceed refLen and a
+	// row never holds more than refLen cells: the arrays are capped at refLen+3 entries and the direction rows at
+	// min(width_d, refLen) cells of ONE byte (bit 0: E opened, bit 1: F opened, bits 2-3: source of H).  A band much wider
+	// than the window (read_begin far from read_end, as after a reverse pass derailed by Q2) therefore costs
+	// readLen * refLen bytes instead of readLen * width_d * 3.
+	const int wcap_max = (scratch_cap >= 65536) ? 4099 : 256;
 	int32_t* h_b = reinterpret_cast<int32_t*>(my);
-	int32_t* e_b = h_b + wmax;
-	int32_t* h_c = e_b + wmax;
-	int8_t* direction = reinterpret_cast<int8_t*>(h_c + wmax);
-	const long dir_cap = (long)scratch_cap - (long)3 * wmax * 4;
 	int band = (refLen > readLen ? refLen - readLen : readLen - refLen) + 1;
-	int maxv = 0, width = 0, width_d = 0;
+	int maxv = 0, width = 0, width_d = 0, stride = 0;
+	const int wcap = refLen + 3 < wcap_max ? refLen + 3 : wcap_max;
+	int32_t* e_b = h_b + wcap;
+	int32_t* h_c = e_b + wcap;
+	uint8_t* direction = reinterpret_cast<uint8_t*>(h_c + wcap);
+	const long dir_cap = (long)scratch_cap - (long)3 * wcap * 4;
+	if (dir_cap <= 0) { o->status = 2; return; }
 	do {
 		width = band * 2 + 3; width_d = band * 2 + 1;
-		if (width + 1 > wmax || (long)width_d * readLen * 3 + 3 > dir_cap) { o->status = 2; return; }
-		for (int j = 1; j < width - 1; j++) h_b[j] = 0;
+		const bool dense = width_d > refLen;              // rows indexed by the column itself
+		stride = dense ? refLen : width_d;
+		const int wuse = width < wcap ? width : wcap;      // entries of the band arrays that can ever be touched
+		if ((width > wcap && refLen + 3 > wcap) || (long)stride * readLen > dir_cap) { o->status = 2; return; }
+		for (int j = 1; j < wuse - 1; j++) h_b[j] = 0;
 		for (int i = 0; i < readLen; i++) {
 			int beg = 0, end = refLen - 1, u = 0;
 			if (i - band > beg) beg = i - band;
 			if (i + band < end) end = i + band;
 			const int edge = end + 1 < width - 1 ? end + 1 : width - 1;
 			int f = 0;
-			h_b[0] = 0; e_b[0] = 0; h_b[edge] = 0; e_b[edge] = 0; h_c[0] = 0;
-			int8_t* line = direction + (long)width_d * i * 3;
+			h_b[0] = 0; e_b[0] = 0; h_c[0] = 0;
+			if (edge < wcap) { h_b[edge] = 0; e_b[edge] = 0; }
+			uint8_t* line = direction + (long)stride * i;
 			const int x = i - band > 0 ? i - band : 0;
 			const int xp = i - 1 - band > 0 ? i - 1 - band : 0;
 			const int rd = read[i];
+			const int lx = dense ? 0 : x;
+			int hleft = 0;                                // h_c[j - x]: the H just written for column j-1 (h_c[0] = 0 at j = beg = x)
+			int hdiag = h_b[beg - xp];                    // h_b[d], d = j - xp
 			for (int j = beg; j <= end; j++) {
 				u = j - x + 1;
-				const int e = j - xp + 1, b = j - x, d = j - xp;
-				int8_t* cell = line + (j - x) * 3;
-				int t1 = i == 0 ? -GAP_OPEN : h_b[e] - GAP_OPEN;
+				const int e = j - xp + 1;
+				const int hbe = h_b[e];
+				int t1 = i == 0 ? -GAP_OPEN : hbe - GAP_OPEN;
 				int t2 = i == 0 ? -GAP_EXT : e_b[e] - GAP_EXT;
 				const int ev = t1 > t2 ? t1 : t2;
 				e_b[u] = ev;
-				const int8_t de = t1 > t2 ? 3 : 2;
-				cell[0] = de;
-				t1 = h_c[b] - GAP_OPEN;
+				const int de = t1 > t2 ? 1 : 0;
+				t1 = hleft - GAP_OPEN;
 				t2 = f - GAP_EXT;
 				f = t1 > t2 ? t1 : t2;
-				const int8_t df = t1 > t2 ? 5 : 4;
-				cell[1] = df;
+				const int df = t1 > t2 ? 1 : 0;
 				const int e1 = ev > 0 ? ev : 0;
 				const int f1 = f > 0 ? f : 0;
 				t1 = e1 > f1 ? e1 : f1;
-				t2 = h_b[d] + swsc(ref[j], rd);
+				t2 = hdiag + swsc(ref[j], rd);
 				const int hv = t1 > t2 ? t1 : t2;
 				h_c[u] = hv;
 				if (hv > maxv) maxv = hv;
-				cell[2] = (t1 <= t2) ? (int8_t)1 : (e1 > f1 ? de : df);
+				const int dh = (t1 <= t2) ? 0 : (e1 > f1 ? 1 : 2);
+				line[j - lx] = (uint8_t)(de | (df << 1) | (dh << 2));
+				hleft = hv; hdiag = hbe;
 			}
 			for (int j = 1; j <= u; j++) h_b[j] = h_c[j];
 		}
@@ -484,6 +515,8 @@ __global__ void __launch_bounds__(64) k_finish(const uint8_t* __restrict__ tcode
 		if (maxv < score && band > 4 * (refLen + readLen) + 16) { o->status = 3; return; }
 	} while (maxv < score);
 	band /= 2;
+	width_d = band * 2 + 1;
+	const bool dense = width_d > refLen;
 	uint32_t rc[ALIGN_MAX_CIGAR];
 	int l = 0;
 	int i = readLen - 1, j = refLen - 1, e = 0, state = 2, op = 0, prev_op = 0, status = 0;
@@ -493,13 +526,16 @@ __global__ void __launch_bounds__(64) k_finish(const uint8_t* __restrict__ tcode
 		if (i - band > beg) beg = i - band;
 		if (i + band < end) end = i + band;
 		if (j < beg || j > end) { status = 3; break; }
-		const int8_t dv = direction[(long)width_d * i * 3 + (j - x) * 3 + state];
+		const uint32_t nib = direction[(long)stride * i + (j - (dense ? 0 : x))];
+		// direction byte of the reference: state 0 (E) -> 3/2, state 1 (F) -> 5/4, state 2 (H) -> 1 or the E/F byte
+		int dv;
+		const int dE = (nib & 1) ? 3 : 2, dF = (nib & 2) ? 5 : 4;
+		if (state == 0) dv = dE; else if (state == 1) dv = dF; else { const int dh = (nib >> 2) & 3; dv = dh == 0 ? 1 : (dh == 1 ? dE : dF); }
 		if (dv == 1) { --i; --j; state = 2; op = 0; }
 		else if (dv == 2) { --i; state = 0; op = 1; }
 		else if (dv == 3) { --i; state = 2; op = 1; }
 		else if (dv == 4) { --j; state = 1; op = 2; }
-		else if (dv == 5) { --j; state = 2; op = 2; }
-		else { status = 1; break; }
+		else { --j; state = 2; op = 2; }
 		if (op == prev_op) ++e;
 		else {
 			if (l >= ALIGN_MAX_CIGAR) { status = 4; break; }

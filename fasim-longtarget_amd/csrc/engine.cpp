@@ -51,12 +51,12 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 
 // FASIM_PROFILE=1: wall-clock accumulators of the host phases, printed to stderr at the end of fasim_scan
 struct HostProf {
-	static constexpr int N = 16;
+	static constexpr int N = 24;
 	double t[N] = { 0 }; const char* name[N] = { nullptr };
 	bool on = false;
 	std::mutex mu;
 	void add(int i, const char* nm, double dt) { if (on) { std::lock_guard<std::mutex> g(mu); t[i] += dt; name[i] = nm; } }
-	void dump() { if (!on) return; for (int i = 0; i < N; i++) if (name[i]) fprintf(stderr, "[fasim prof] %-28s %8.3f s\n", name[i], t[i]); }
+	void dump() { if (!on) return; for (int i = 0; i < N; i++) if (name[i]) fprintf(stderr, "[fasim prof] %-60s %12.6f\n", name[i], t[i]); }
 	void reset() { for (int i = 0; i < N; i++) { t[i] = 0; name[i] = nullptr; } }
 };
 HostProf g_prof;
@@ -418,7 +418,7 @@ struct WindowProb { int unit, t0, len; };
 int run_finish(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, const std::vector<FwdOut>& fo,
 	std::vector<AlignResult>& out, std::vector<uint32_t>& cigars, std::vector<char>& status);
 bool align_v2_fits(const fasim_engine* E, const std::vector<WindowProb>& W);
-int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, std::vector<FwdOut>& fo);
+int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, std::vector<FwdOut>& fo, bool word);
 
 // a9-a11: ssw_align for a list of windows (forward + reverse on the GPU, 16-bit re-runs, banded traceback)
 int run_align(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, std::vector<AlignResult>& out,
@@ -449,7 +449,7 @@ int run_align(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>
 		for (size_t r = 0; r < redo.size(); r++) W2[r] = W[redo[r]];
 		if (align_v2_fits(E, W2)) {
 			std::vector<FwdOut> f2;
-			rc = run_fwd(E, B, W2, f2); if (rc) return rc;
+			rc = run_fwd(E, B, W2, f2, true); if (rc) return rc;
 			for (size_t r = 0; r < redo.size(); r++) {
 				AlignEnds& e = ends[redo[r]];
 				e.score_fwd = f2[r].score; e.ref_end = f2[r].ref_end; e.read_end = f2[r].read_end;
@@ -567,7 +567,9 @@ bool align_v2_fits(const fasim_engine* E, const std::vector<WindowProb>& W)
 }
 
 // forward pass of every window (k_build_stream + k_align_fwd): score, ref_end, read_end, hazard flag
-int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, std::vector<FwdOut>& fo)
+// word = false: the reference's 8-bit pass (taint-tracking kernel; scores from 251 on only mean "overflow");
+// word = true : its 16-bit pass (plain kernel, exact scores up to 980, flags always 0)
+int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, std::vector<FwdOut>& fo, bool word)
 {
 	const int n = (int)W.size();
 	fo.resize(n);
@@ -596,7 +598,7 @@ int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& 
 	FwdLaunch L;
 	L.stream = E->fstream.as<uint8_t>(); L.probs = E->fprobs.as<FwdProb>(); L.task_first = E->ftasks.as<int32_t>();
 	L.ntask = (int)tasks.size() - 1; L.counter = E->counter.as<uint32_t>(); L.qcodes = E->q2.as<uint8_t>(); L.m = E->m;
-	L.out = E->fout.as<FwdOut>();
+	L.out = E->fout.as<FwdOut>(); L.word = word ? 1 : 0;
 	L.boundary = nullptr;
 	if (systolic_tiles(E->m) > 1) { HIPOK(E->fboundary.ensure(((size_t)off + 256) * sizeof(uint4))); L.boundary = E->fboundary.as<uint4>(); }
 	{ TimedScope ts(E, 2); he = launch_align_fwd(L, E->st); }
@@ -609,6 +611,24 @@ int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& 
 	HIPOK(hipMemcpyAsync(fo.data(), E->fout.p, sizeof(FwdOut) * n, hipMemcpyDeviceToHost, E->st));
 	HIPOK(hipStreamSynchronize(E->st));
 	g_prof.add(3, "run_fwd D2H", now_s() - tp);
+	return FASIM_OK;
+}
+
+// Forward pass as ssw_align runs it: the 8-bit pass first; a maximum of 251 or more overflows the reference's 8-bit
+// kernel, which then repeats the whole alignment with its 16-bit kernels (sswNew.cpp:1473-1477, no overflow rule,
+// unsigned-safe compare) -> second pass with the plain systolic kernel for those windows (flags = 4).  A window
+// whose winning cell is tainted (flags & 1) is not trusted either way: the caller replays it exactly.
+int run_fwd_both(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, std::vector<FwdOut>& fo, int64_t* word_reruns)
+{
+	int rc = run_fwd(E, B, W, fo, false); if (rc) return rc;
+	std::vector<int> ov;
+	for (size_t i = 0; i < fo.size(); i++) if (!(fo[i].flags & 1) && fo[i].score >= 255 - BIAS) ov.push_back((int)i);
+	if (ov.empty()) return FASIM_OK;
+	std::vector<WindowProb> W2(ov.size()); std::vector<FwdOut> f2;
+	for (size_t r = 0; r < ov.size(); r++) W2[r] = W[ov[r]];
+	rc = run_fwd(E, B, W2, f2, true); if (rc) return rc;
+	for (size_t r = 0; r < ov.size(); r++) { fo[ov[r]] = f2[r]; fo[ov[r]].flags = 4; }
+	if (word_reruns) *word_reruns += (int64_t)ov.size();
 	return FASIM_OK;
 }
 
@@ -683,15 +703,19 @@ int run_finish(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb
 	HIPOK(hipMemcpyAsync(ao.data(), E->aout.p, sizeof(AlignOutDev) * n, hipMemcpyDeviceToHost, E->st));
 	HIPOK(hipStreamSynchronize(E->st));
 	{
-		// alignments whose band / direction matrix did not fit the LDS kernel: same algorithm on global scratch
-		std::vector<int32_t> big;
-		for (int k = 0; k < n; k++) if (ao[k].status == 2) big.push_back(k);
-		if (!big.empty()) {
+		// alignments whose band / direction matrix did not fit the LDS kernel: same algorithm on global scratch, first
+		// with 16 KB per alignment, then (wide bands after several doublings: gapped alignments) with 1 MB
+		const int caps[2] = { scratch_cap, 1 << 20 };
+		for (int pass = 0; pass < 2; pass++) {
+			std::vector<int32_t> big;
+			for (int k = 0; k < n; k++) if (ao[k].status == 2) big.push_back(k);
+			if (big.empty()) break;
+			if (g_prof.on) g_prof.add(17 + pass, pass ? "finish: alignments sent to the 1 MB pass (count)" : "finish: alignments sent to the 16 KB pass (count)", 1e-6 * big.size());
 			rc = upload(E, E->unit_ids, big.data(), sizeof(int32_t) * big.size()); if (rc) return rc;
-			HIPOK(E->scratch2.ensure(big.size() * (size_t)scratch_cap));
+			HIPOK(E->scratch2.ensure(big.size() * (size_t)caps[pass]));
 			{ TimedScope ts(E, 6);
 			he = launch_finish_big(E->tcodes.as<uint8_t>(), E->q2.as<uint8_t>(), E->fprobs.as<FwdProb>(), E->fout.as<FwdOut>(),
-				E->unit_ids.as<int32_t>(), (int)big.size(), E->scratch2.as<uint8_t>(), scratch_cap, E->aout.as<AlignOutDev>(),
+				E->unit_ids.as<int32_t>(), (int)big.size(), E->scratch2.as<uint8_t>(), caps[pass], E->aout.as<AlignOutDev>(),
 				E->cigpool.as<uint32_t>(), (uint32_t)pool_cap, E->cigcount.as<uint32_t>(), E->st); }
 			if (he != hipSuccess) return fail(E, FASIM_E_HIP, "finish (global scratch) launch failed: %s", hipGetErrorString(he));
 			HIPOK(hipMemcpyAsync(ao.data(), E->aout.p, sizeof(AlignOutDev) * n, hipMemcpyDeviceToHost, E->st));
@@ -709,6 +733,16 @@ int run_finish(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb
 	}
 	for (int k = 0; k < n; k++) {
 		const AlignOutDev& a = ao[k];
+		if (g_prof.on && (a.status == 2 || a.status == 3)) {
+			static std::atomic<int> shown(0);
+			if (shown.fetch_add(1) < 12) fprintf(stderr, "[finish status %d] unit %d t0 %d score %d fwd(ref_end %d read_end %d flags %d) out(ref_begin %d q_begin %d) win_len %d\n",
+				(int)a.status, W[k].unit, W[k].t0, fo[k].score, fo[k].ref_end, fo[k].read_end, fo[k].flags, a.ref_begin, a.query_begin, W[k].len);
+		}
+		if (g_prof.on && a.status != 0) {
+			static const char* nm[5] = { "finish: device status 2 (count)", "finish: device status 4 (count)", "finish: device status 10 (count)", "finish: device status 11 (count)", "finish: device status 1/3 (count)" };
+			const int si = a.status == 2 ? 0 : a.status == 4 ? 1 : a.status == 10 ? 2 : a.status == 11 ? 3 : 4;
+			g_prof.add(19 + si, nm[si], 1e-6);
+		}
 		if (a.status == 2 || a.status == 4 || a.status == 10 || a.status == 11) { status[k] = 2; continue; }
 		if (a.status == 1 || a.status == 3) { status[k] = 1; continue; }
 		AlignResult& r = out[k];
@@ -728,7 +762,7 @@ int run_align_v2(fasim_engine* E, const UnitBatch& B, const std::vector<WindowPr
 	if (!n) { out.clear(); return FASIM_OK; }
 	if (!align_v2_fits(E, W)) return run_align(E, B, W, out, cigars, stats);
 	std::vector<FwdOut> fo;
-	int rc = run_fwd(E, B, W, fo); if (rc) return rc;
+	int rc = run_fwd_both(E, B, W, fo, stats ? &stats->align_word_reruns : nullptr); if (rc) return rc;
 	{
 		std::vector<int> rv;
 		for (int k = 0; k < n; k++) if (!fo[k].flags && fo[k].score >= 148 && fo[k].score < 255 - BIAS) rv.push_back(k);
@@ -744,7 +778,7 @@ int run_align_v2(fasim_engine* E, const UnitBatch& B, const std::vector<WindowPr
 		std::vector<AlignResult> r2;
 		rc = run_align(E, B, W2, r2, cigars, nullptr); if (rc) return rc;
 		for (size_t i = 0; i < redo.size(); i++) out[redo[i]] = r2[i];
-		if (stats) stats->align_word_reruns += (int64_t)redo.size();
+		if (stats) stats->exact_replays += (int64_t)redo.size();
 	}
 	return FASIM_OK;
 }
@@ -1131,7 +1165,7 @@ int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t*
 				st.align_calls += (int64_t)W.size();
 				for (const WindowProb& w : W) st.cells_stage3 += (int64_t)E->m * w.len;
 				std::vector<FwdOut> fo;
-				rc = run_fwd(E, B, W, fo); if (rc) return rc;
+				rc = run_fwd_both(E, B, W, fo, &st.align_word_reruns); if (rc) return rc;
 				{
 					// score >= 148: the REVERSE pass (its own stripe geometry) could hit Q2 -> exact reverse pass now,
 					// so that sw_score = min(forward, reverse) is known before the decision
@@ -1145,7 +1179,10 @@ int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t*
 					const FwdOut& f = fo[i];
 					// flag 1: the forward pass may hit Q2 (or the exact reverse pass was unusable); scores >= 251 go through
 					// the reference's 16-bit kernels: both are replayed on the stripe-faithful path
-					if ((f.flags & 1) || (!(f.flags & 2) && f.score >= 148)) { x.exact = 1; x.done = 1; continue; }
+					if ((f.flags & 1) || (!(f.flags & 6) && f.score >= 148)) {
+						if (g_prof.on) { if (f.flags & 1) g_prof.add(8 + it, "exact: forward winner tainted / reverse unusable (count)", 1e-6); else g_prof.add(12, "exact: score >= 148 without exact reverse (count)", 1e-6); }
+						x.exact = 1; x.done = 1; continue;
+					}
 					x.fsel = f;                                                                        // "last tried" so far
 					if (f.score >= x.c.score) { x.flag = 1; x.done = 1; continue; }                    // fastsim.h:218-221
 					if (f.score > x.fbest.score && f.ref_end == x.cut - 1) { x.fbest = f; x.bestcut = x.cut; x.flag = 2; }   // :222-235
@@ -1164,7 +1201,7 @@ int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t*
 			rc = run_finish(E, B, W, fsel, res, cigars, status); if (rc) return rc;
 			for (size_t i = 0; i < who.size(); i++) {
 				CandState& x = cs[who[i]];
-				if (status[i] != 0) { x.exact = 1; continue; }
+				if (status[i] != 0) { if (g_prof.on) { static const char* nm[6] = { "exact: finish status 0", "exact: finish status 1 (count)", "exact: finish status 2 (count)", "exact: finish status 3 (count)", "exact: finish status 4 (count)", "exact: finish status >= 5 (count)" }; const int si = std::min(5, (int)status[i]); g_prof.add(13 + si, nm[si], 1e-6); } x.exact = 1; continue; }
 				x.al = res[i];
 				st.cells_stage3 += (int64_t)(x.al.ref_end - x.al.ref_begin + 1) * (x.al.query_end - x.al.query_begin + 1);
 			}
@@ -1173,7 +1210,7 @@ int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t*
 		{
 			std::vector<int> ex;
 			for (size_t k = 0; k < cs.size(); k++) if (!v2 || cs[k].exact) { ex.push_back((int)k); cs[k].done = 0; cs[k].flag = 0; cs[k].best = AlignResult(); cs[k].al = AlignResult(); }
-			if (v2) st.align_word_reruns += (int64_t)ex.size();
+			if (v2) st.exact_replays += (int64_t)ex.size();
 			for (int it = 0; it < 4 && !ex.empty(); it++) {
 				std::vector<WindowProb> W; std::vector<int> who;
 				for (int k : ex) {
@@ -1343,7 +1380,7 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 			st.align_calls += x.align_calls; st.align_word_reruns += x.align_word_reruns; st.stage2_overflow_units += x.stage2_overflow_units;
 			st.stage1_word_reruns += x.stage1_word_reruns; st.logical_cells += x.logical_cells; st.t_stage1_s += x.t_stage1_s;
 			st.t_stage2_s += x.t_stage2_s; st.t_stage3_s += x.t_stage3_s; st.t_host_s += x.t_host_s; st.cells_stage1 += x.cells_stage1;
-			st.cells_stage2 += x.cells_stage2; st.cells_stage3 += x.cells_stage3; st.hazard_units += x.hazard_units; st.rev_exact += x.rev_exact;
+			st.cells_stage2 += x.cells_stage2; st.cells_stage3 += x.cells_stage3; st.hazard_units += x.hazard_units; st.rev_exact += x.rev_exact; st.exact_replays += x.exact_replays;
 			drain_timed(ws[wi]);
 			for (int k = 0; k < 8; k++) { st.kernel_ms[k] += ws[wi]->kernel_ms[k]; st.kernel_launches[k] += ws[wi]->kernel_launches[k]; }
 		}

@@ -61,6 +61,7 @@ struct FwdLaunch {
 	const uint8_t* stream; const FwdProb* probs; const int32_t* task_first; int32_t ntask; uint32_t* counter;
 	const uint8_t* qcodes; int32_t m; FwdOut* out;
 	uint4* boundary;      // [stream position] hand-over between query tiles; needed when systolic_tiles(m) > 1
+	int32_t word;         // 1: the reference's 16-bit pass (no overflow rule, no Q2): plain variant without taint tracking
 };
 hipError_t launch_build_stream(const uint8_t* tcodes, const FwdProb* probs, int32_t nprob, uint8_t* stream, hipStream_t st);
 hipError_t launch_align_fwd(const FwdLaunch& L, hipStream_t st);     // hipErrorInvalidValue: query too long

@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(64) k_striped(StripedArgs a)
 				if (!WORD && maxv + BIAS >= 255) { overflow = true; stop = true; }   // sswNew.cpp:386 / stats.h:729
 				else {
 					end_ref = i;
-					if constexpr (MODE == MODE_ALIGN) {
+					if constexpr (MODE == MODE_ALIGN || MODE == MODE_REV) {
 						// smallest row whose stored H equals the new maximum (sswNew.cpp:621-629)
 						int best = 0x7fffffff;
 						if (part) {

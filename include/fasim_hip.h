@@ -98,8 +98,7 @@ typedef struct fasim_triplex {
 typedef struct fasim_scan_stats {
 	int64_t segments, segments_skipped, units;
 	int64_t candidates, align_calls;
-	int64_t align_word_reruns;          /* window alignments re-run on the stripe-faithful kernels (possible Q2,
-	                                       16-bit re-runs, undecided reverse passes)                              */
+	int64_t align_word_reruns;          /* window alignments repeated with the 16-bit pass (8-bit maximum >= 251) */
 	int64_t stage2_overflow_units, stage1_word_reruns;
 	int64_t logical_cells;              /* m * sum(len(segment)) * n_enc                  */
 	double  t_total_s, t_stage1_s, t_stage2_s, t_stage3_s, t_host_s;   /* host wall clock per phase       */
@@ -112,6 +111,7 @@ typedef struct fasim_scan_stats {
 	int64_t cells_stage1, cells_stage2, cells_stage3;   /* DP cells actually executed (stage 3: fwd + rev)   */
 	int64_t hazard_units;               /* units re-run by the stripe-faithful kernel (possible Q2)  */
 	int64_t rev_exact;                  /* window tries whose reverse pass ran on the stripe-faithful kernel */
+	int64_t exact_replays;              /* candidates replayed try by try on the stripe-faithful kernels */
 } fasim_scan_stats;
 
 typedef struct fasim_result {

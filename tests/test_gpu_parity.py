@@ -205,6 +205,12 @@ def test_rnd30k_tfosorted_and_sharding(mod, engine, h19, golden_dir):
     whole = engine.scan(dna, p)
     gold = open(os.path.join(golden_dir, "rnd30k.TFOsorted"), "rb").read()
     assert mod.tfosorted(whole, "chrS", 1, p) == gold
+    # the systolic path must carry the work: stripe-faithful re-runs / replays are the rare exception on random DNA
+    # (a broken fast path is invisible in the records, because everything it cannot decide is replayed exactly)
+    st = whole.stats
+    assert st["kernel_launches"][0] > 0 and st["kernel_launches"][2] > 0
+    assert st["hazard_units"] * 20 <= st["units"], st
+    assert st["exact_replays"] * 50 <= st["candidates"], st
     # the same scan as 3 contiguous shards (what 3 ranks would do), merged in rank order
     nseg = mod.segment_count(len(dna), p)
     cuts = [0, nseg // 3, 2 * nseg // 3, nseg]
