@@ -80,7 +80,7 @@ struct fasim_engine {
 	// launch a heavy kernel at once, the kernels share the GPU and end together, and then nothing heavy runs while all
 	// workers do their latency-bound tail kernels and host work.  With at most `cap` heavy kernels in flight each one
 	// runs at full speed and the workers stay staggered.
-	struct HeavyGate { std::mutex m; std::condition_variable cv; int in_flight = 0; int cap = 2; };
+	struct HeavyGate { std::mutex m; std::condition_variable cv; int in_flight = 0; int cap = 3; };
 	HeavyGate own_gate;
 	HeavyGate* gate = nullptr;            // shared by the workers of one fasim_scan (points at the parent's own_gate)
 	int host_threads_total = 1;
@@ -1343,7 +1343,7 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 		for (int k = 0; k < nworkers - 1; k++) ws.push_back(E->workers[k]);
 		{
 			const char* envg = getenv("FASIM_HEAVY_GATE");      // heavy kernels in flight at once (0 = no gate)
-			E->own_gate.cap = envg ? atoi(envg) : 2;
+			E->own_gate.cap = envg ? atoi(envg) : 3;
 		}
 		for (fasim_engine* w : ws) {
 			w->gate = (ws.size() > 1 && E->own_gate.cap > 0) ? &E->own_gate : nullptr;
