@@ -168,35 +168,36 @@ def main():
     if rank == 0:
         m = len(rna)
         units_per_step = agg["units"] / args.steps
-        # dominant kernel by HIP-event time
         kms = agg["kernel_ms"]
-        dom = max(range(8), key=lambda i: kms[i])
-        launches = max(1, agg["kernel_launches"][dom])
-        avg_ms = kms[dom] / launches
         n_avg = agg["cells_stage2"] / max(1, agg["units"]) / m        # mean segment length
-        if dom == 0:      # k_scan: segment codes (n) + u16 column maxima (2n) + int8-equivalent profile (5m) per unit
-            bytes_per_unit, units_dom = 3 * n_avg + 5 * m, agg["units"] + agg["stage1_word_reruns"]
-            cells_dom, ops_per_cell = agg["cells_stage2"], 5.5
-        elif dom == 1:    # stripe-faithful re-runs of hazard units: n codes + n u8 maxima + profile
-            bytes_per_unit, units_dom = 2 * n_avg + 5 * m, max(1, agg["hazard_units"])
-            cells_dom, ops_per_cell = agg["cells_stage2"] * agg["hazard_units"] / max(1, agg["units"]), 15
-        else:             # window alignments: L codes + profile + 24-byte result per try
-            calls = max(1, agg["align_calls"])
-            bytes_per_unit, units_dom = agg["cells_stage3"] / m / calls + 5 * m + 24, calls
-            cells_dom, ops_per_cell = agg["cells_stage3"], 6
-        alg_bytes_per_launch = bytes_per_unit * units_dom / launches
-        # HBM traffic from the PMC passes (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate
-        # rocprofv3 --pmc runs, FETCH doubled per the gfx950 note), scaled to the units one launch of this build processes
-        traffic = None
-        traffic_per_unit = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            traffic_per_unit = pmc["k_scan"]["hbm_bytes_per_unit"]
-            if dom == 0:
-                traffic = int(traffic_per_unit * units_dom / launches)
         except Exception:
-            traffic = None
-        achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            pmc = {}
+
+        def kernel_roofline(idx):
+            """HBM roofline of one of the two DP kernels: algorithmic bytes per launch / HIP-event launch duration."""
+            launches_k = max(1, agg["kernel_launches"][idx])
+            avg = kms[idx] / launches_k
+            if idx == 0:   # k_scan, per unit: segment codes in (n) + u16 column maxima out (2n); the profile is LDS-resident
+                per_item, items, key = 3 * n_avg, agg["units"] + agg["stage1_word_reruns"], "k_scan"
+            else:          # k_align_fwd, per window try: L + 2 stream bytes in, 16-byte descriptor in, 24-byte result out
+                calls = max(1, agg["align_calls"])
+                per_item, items, key = agg["cells_stage3"] / m / calls + 2 + 16 + 24, calls + agg["align_word_reruns"], "k_align_fwd"
+            alg = per_item * items / launches_k
+            tr = pmc.get(key, {}).get("hbm_bytes_per_item")
+            return {"bound": "hbm", "kernel": KERNEL_NAMES[idx], "achieved": round(alg / (avg * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                    "traffic": int(tr * items / launches_k) if tr else None, "avg_launch_ms": round(avg, 3), "launches": int(launches_k),
+                    "algorithmic_bytes_per_launch": int(alg),
+                    "note": "integer DP is VALU-bound by construction; see valu"}
+
+        # dominant kernel: k_scan (fused stage 1+2: most DP cells; its time and k_align_fwd's are within a few percent)
+        dom = 0
+        launches = max(1, agg["kernel_launches"][dom])
+        avg_ms = kms[dom] / launches
+        cells_dom, ops_per_cell = agg["cells_stage2"], 5.0
+        traffic_per_unit = pmc.get("k_scan", {}).get("hbm_bytes_per_unit")
         out = {
             "metric": "SW Gcells/s (logical, whole job: stage 1+2+3 of the triplex scan)",
             "value": round(total_cells / tmax / 1e9, 3),
@@ -220,11 +221,8 @@ def main():
             "kernel_launches": {KERNEL_NAMES[i]: int(agg["kernel_launches"][i]) for i in range(7)},
             "counts": {k: int(agg[k]) for k in ("segments", "units", "candidates", "align_calls", "hazard_units", "rev_exact", "exact_replays",
                                                 "align_word_reruns", "stage2_overflow_units")},
-            "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "avg_launch_ms": round(avg_ms, 3), "launches": int(launches),
-                         "algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
-                         "note": "integer DP is VALU-bound by construction; see valu"},
+            "roofline": kernel_roofline(0),
+            "roofline_stage3": kernel_roofline(2),
             "valu": {"kernel": KERNEL_NAMES[dom], "gcells_per_s": round(cells_dom / (kms[dom] * 1e-3) / 1e9, 2),
                      "ops_per_cell": ops_per_cell, "achieved_tops": round(cells_dom * ops_per_cell / (kms[dom] * 1e-3) / 1e12, 3),
                      "peak_tops": VALU_PEAK_TOPS,
@@ -237,11 +235,12 @@ def main():
         ik = iso["kernel_ms"]
         out["isolated_kernels"] = {
             "what": f"untimed pass over the first {iso['segments']} segments with ONE batch in flight (kernels run alone)",
+            "units": iso["units"], "align_calls": iso["align_calls"],
             "k_scan": {"ms": round(ik[0], 2), "gcells_per_s": round(iso["cells_stage2"] / (ik[0] * 1e-3) / 1e9, 1),
-                       "valu_frac": round(iso["cells_stage2"] * 5.5 / (ik[0] * 1e-3) / 1e12 / VALU_PEAK_TOPS, 4),
+                       "valu_frac": round(iso["cells_stage2"] * 5.0 / (ik[0] * 1e-3) / 1e12 / VALU_PEAK_TOPS, 4),
                        "hbm_GBps": round((traffic_per_unit or 0) * iso["units"] / (ik[0] * 1e-3) / 1e9, 2)},
             "k_align_fwd": {"ms": round(ik[2], 2), "gcells_per_s": round(iso["align_calls"] and iso["cells_stage3"] / (ik[2] * 1e-3) / 1e9, 1),
-                            "valu_frac": round(iso["cells_stage3"] * 6 / (ik[2] * 1e-3) / 1e12 / VALU_PEAK_TOPS, 4)},
+                            "valu_frac": round(iso["cells_stage3"] * 5.5 / (ik[2] * 1e-3) / 1e12 / VALU_PEAK_TOPS, 4)},
             "k_striped_hazard_reruns_ms": round(ik[1], 2), "k_finish_lds_ms": round(ik[3], 2),
             "k_striped_exact_replays_ms": round(ik[5], 2), "k_finish_k_banded_global_ms": round(ik[6], 2),
         }
