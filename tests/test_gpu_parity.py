@@ -234,6 +234,30 @@ def test_cli_driver_writes_identical_file(golden_dir, tmp_path):
         assert got == open(os.path.join(golden_dir, f"demo_lg40.TFOclass{level}"), "rb").read()
 
 
+def test_cli_all_records_streams_a_multi_record_file(golden_dir, tmp_path):
+    """--all-records: every record of a multi-record DNA file is scanned on its own (one in memory at a time) and gets
+    its own output files, each identical to what the reference writes for that record alone."""
+    exe = os.path.join(entry.PKG_DIR, "fasim")
+    both = open(os.path.join(golden_dir, "testDNA.fa"), "rb").read().rstrip(b"\n") + b"\n" + \
+        open(os.path.join(golden_dir, "planted40k.fa"), "rb").read()
+    (tmp_path / "two.fa").write_bytes(both)
+    (tmp_path / "H19.fa").write_bytes(open(os.path.join(golden_dir, "H19.fa"), "rb").read())
+    (tmp_path / "out").mkdir()
+    subprocess.run([exe, "-f1", "two.fa", "-f2", "H19.fa", "-O", "out/", "-lg", "40", "--all-records"], cwd=tmp_path, check=True,
+                   stdout=subprocess.DEVNULL)
+    for stem, gold in (("hg19-H19-two.chr11", "demo_lg40"), ("syn-H19-two.chrP", "planted40k")):
+        assert (tmp_path / "out" / f"{stem}-TFOsorted").read_bytes() == open(os.path.join(golden_dir, gold + ".TFOsorted"), "rb").read()
+        for level in (1, 2):
+            got = (tmp_path / "out" / f"{stem}-TFOclass{level}-15-40").read_bytes()
+            assert got == open(os.path.join(golden_dir, f"{gold}.TFOclass{level}"), "rb").read()
+    # without the flag only the first record is scanned (and named as the reference names it)
+    (tmp_path / "out1").mkdir()
+    r = subprocess.run([exe, "-f1", "two.fa", "-f2", "H19.fa", "-O", "out1/", "-lg", "40"], cwd=tmp_path, check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    assert b"more than one record" in r.stderr
+    assert (tmp_path / "out1" / "hg19-H19-two-TFOsorted").read_bytes() == open(os.path.join(golden_dir, "demo_lg40.TFOsorted"), "rb").read()
+
+
 def test_live_reference_probe_random_vectors(engine, oracle_build):
     """If the compiled reference travelled with the repo (oracle/_ref), compare fresh random vectors too."""
     if not helpers.have_ref_probe():
