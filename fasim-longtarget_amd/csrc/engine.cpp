@@ -67,6 +67,7 @@ struct ProfScope { int i; const char* nm; double t0; ProfScope(int i_, const cha
 struct fasim_engine {
 	int device = 0;
 	hipStream_t st = nullptr;
+	hipStream_t st_heavy = nullptr;   // stream of k_scan / k_align_fwd; == st unless FASIM_LIGHT_CUS reserves CUs for the other kernels
 	std::string err;
 	std::string rna;
 	int m = 0;
@@ -145,8 +146,9 @@ hipEvent_t get_event(fasim_engine* E)
 }
 struct TimedScope {
 	fasim_engine* E; hipEvent_t a = nullptr, b = nullptr; int family;
-	TimedScope(fasim_engine* e, int fam) : E(e), family(fam) { a = get_event(E); b = get_event(E); if (a) (void)hipEventRecord(a, E->st); }
-	~TimedScope() { if (a && b) { (void)hipEventRecord(b, E->st); E->timed.push_back({ a, b, family }); } }
+	hipStream_t s;
+	TimedScope(fasim_engine* e, int fam, hipStream_t stream = nullptr) : E(e), family(fam), s(stream ? stream : e->st) { a = get_event(E); b = get_event(E); if (a) (void)hipEventRecord(a, s); }
+	~TimedScope() { if (a && b) { (void)hipEventRecord(b, s); E->timed.push_back({ a, b, family }); } }
 };
 // call after a stream synchronisation
 void drain_timed(fasim_engine* E)
@@ -300,9 +302,11 @@ int run_scan_v2(fasim_engine* E, const UnitBatch& B, const std::vector<char>& un
 		// alphabet differs (Q4), so the exact stage-1 maximum needs its own pass
 		rc = upload(E, E->unit_ids, sep.data(), sizeof(int32_t) * sep.size()); if (rc) return rc;
 		L.unit_ids = E->unit_ids.as<int32_t>(); L.nwork = (int)sep.size(); L.qcodes = E->q1.as<uint8_t>(); fill_scores(L.score, true);
-		{ TimedScope ts(E, 0); he = launch_scan(L, E->st); }
+		if (E->st_heavy != E->st) HIPOK(hipStreamSynchronize(E->st));
+		{ TimedScope ts(E, 0, E->st_heavy); he = launch_scan(L, E->st_heavy); }
 		if (he == hipErrorInvalidValue) return 1;
 		if (he != hipSuccess) return fail(E, FASIM_E_HIP, "scan (stage-1 pass) launch failed: %s", hipGetErrorString(he));
+		if (E->st_heavy != E->st) HIPOK(hipStreamSynchronize(E->st_heavy));
 		he = launch_max16(E->colmax16.as<uint16_t>(), E->unit_ids.as<int32_t>(), (int)sep.size(), E->unit_len.as<int32_t>(),
 			B.tstride, E->stage1_in.as<int32_t>(), E->st);
 		if (he != hipSuccess) return fail(E, FASIM_E_HIP, "max16 launch failed: %s", hipGetErrorString(he));
@@ -314,12 +318,13 @@ int run_scan_v2(fasim_engine* E, const UnitBatch& B, const std::vector<char>& un
 	HIPOK(E->unit_hz.ensure(sizeof(int32_t) * nu));
 	HIPOK(hipMemsetAsync(E->unit_hz.p, 0, sizeof(int32_t) * nu, E->st));
 	L.unit_hz = E->unit_hz.as<int32_t>();
+	if (E->st_heavy != E->st) HIPOK(hipStreamSynchronize(E->st));      // k_encode and the memset above ran on the other stream
 	{
 		GateScope gate(E);
-		{ TimedScope ts(E, 0); he = launch_scan(L, E->st); }
+		{ TimedScope ts(E, 0, E->st_heavy); he = launch_scan(L, E->st_heavy); }
 		if (he == hipErrorInvalidValue) return 1;
 		if (he != hipSuccess) return fail(E, FASIM_E_HIP, "scan launch failed: %s", hipGetErrorString(he));
-		HIPOK(hipStreamSynchronize(E->st));
+		HIPOK(hipStreamSynchronize(E->st_heavy));
 	}
 
 	HIPOK(E->hit_off.ensure(sizeof(int32_t) * nu)); HIPOK(E->hit_cnt.ensure(sizeof(int32_t) * nu));
@@ -593,7 +598,8 @@ int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& 
 	HIPOK(E->fstream.ensure((size_t)off + 256));
 	HIPOK(E->fout.ensure(sizeof(FwdOut) * n));
 	GateScope gate(E);
-	hipError_t he = launch_build_stream(E->tcodes.as<uint8_t>(), E->fprobs.as<FwdProb>(), n, E->fstream.as<uint8_t>(), E->st);
+	if (E->st_heavy != E->st) HIPOK(hipStreamSynchronize(E->st));
+	hipError_t he = launch_build_stream(E->tcodes.as<uint8_t>(), E->fprobs.as<FwdProb>(), n, E->fstream.as<uint8_t>(), E->st_heavy);
 	if (he != hipSuccess) return fail(E, FASIM_E_HIP, "build_stream launch failed: %s", hipGetErrorString(he));
 	FwdLaunch L;
 	L.stream = E->fstream.as<uint8_t>(); L.probs = E->fprobs.as<FwdProb>(); L.task_first = E->ftasks.as<int32_t>();
@@ -601,10 +607,10 @@ int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& 
 	L.out = E->fout.as<FwdOut>(); L.word = word ? 1 : 0;
 	L.boundary = nullptr;
 	if (systolic_tiles(E->m) > 1) { HIPOK(E->fboundary.ensure(((size_t)off + 256) * sizeof(uint4))); L.boundary = E->fboundary.as<uint4>(); }
-	{ TimedScope ts(E, 2); he = launch_align_fwd(L, E->st); }
+	{ TimedScope ts(E, 2, E->st_heavy); he = launch_align_fwd(L, E->st_heavy); }
 	if (he != hipSuccess) return fail(E, FASIM_E_HIP, "align_fwd launch failed: %s", hipGetErrorString(he));
 	tp = now_s();
-	HIPOK(hipStreamSynchronize(E->st));
+	HIPOK(hipStreamSynchronize(E->st_heavy));
 	gate.release();
 	g_prof.add(2, "run_fwd kernel wait", now_s() - tp);
 	tp = now_s();
@@ -834,7 +840,19 @@ int fasim_engine_create(int device, fasim_engine** out)
 	fasim_engine* E = new fasim_engine();
 	E->device = device;
 	he = hipSetDevice(device);
-	if (he == hipSuccess) he = hipStreamCreate(&E->st);
+	{
+		// FASIM_LIGHT_CUS=N: reserve N of the 256 CUs (spread evenly) for the latency-bound kernels; k_scan / k_align_fwd
+		// run on the others through a second, CU-masked stream
+		const char* envl = getenv("FASIM_LIGHT_CUS");
+		const int nl = envl ? atoi(envl) : 0;
+		if (he == hipSuccess && nl > 0 && nl < 256) {
+			uint32_t light[8] = { 0 }, heavy[8] = { 0 };
+			const int every = 256 / nl;
+			for (int cu = 0; cu < 256; cu++) { const bool l = (cu % every) == every - 1 && (cu / every) < nl; (l ? light : heavy)[cu >> 5] |= 1u << (cu & 31); }
+			he = hipExtStreamCreateWithCUMask(&E->st, 8, light);
+			if (he == hipSuccess) he = hipExtStreamCreateWithCUMask(&E->st_heavy, 8, heavy);
+		} else if (he == hipSuccess) { he = hipStreamCreate(&E->st); E->st_heavy = E->st; }
+	}
 	if (he != hipSuccess) { int rc = fail(nullptr, FASIM_E_NODEVICE, "cannot initialise device %d: %s", device, hipGetErrorString(he)); delete E; return rc; }
 	E->lut1 = make_lut(true); E->lut2 = make_lut(false);
 	std::vector<uint8_t> lut(48 * 256);
@@ -865,6 +883,7 @@ void fasim_engine_destroy(fasim_engine* e)
 	for (auto& t : e->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
 	for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
 	for (DevBuf* b : bufs) b->release();
+	if (e->st_heavy && e->st_heavy != e->st) (void)hipStreamDestroy(e->st_heavy);
 	if (e->st) (void)hipStreamDestroy(e->st);
 	delete e;
 }
@@ -1325,13 +1344,24 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 		const char* envw = getenv("FASIM_WORKERS");
 		if (envw) nworkers = std::max(1, std::min(16, atoi(envw)));
 		if (E->opt_workers > 0) nworkers = std::min(16, E->opt_workers);
-		// chunks of at most seg_batch segments; their number is rounded up to a multiple of the worker count so that all
-		// workers finish together (a step of 20 batches on 12 workers would otherwise end with 8 of them idle)
-		int64_t nchunks = (seg_count + seg_batch - 1) / seg_batch;
-		if (nchunks > nworkers) nchunks = (nchunks + nworkers - 1) / nworkers * nworkers;
-		const int64_t per_chunk_segs = (seg_count + nchunks - 1) / std::max<int64_t>(1, nchunks);
+		// Fixed chunks of seg_batch segments.  FASIM_GUIDED=g (> 0) switches to guided self-scheduling (a chunk is about
+		// remaining / (g * workers), at least 64 segments) to shorten the tail of a scan; measured slower on the 50 Mb
+		// workload (every batch pays ~12 host round trips, so smaller batches cost more than the shorter tail saves).
+		static const double guided = [] { const char* e = getenv("FASIM_GUIDED"); return e ? atof(e) : 0.0; }();
 		std::vector<std::pair<int64_t, int64_t>> chunks;
-		for (int64_t b0 = seg_first; b0 < seg_first + seg_count; b0 += per_chunk_segs) chunks.push_back({ b0, std::min(seg_first + seg_count, b0 + per_chunk_segs) });
+		{
+			int64_t b0 = seg_first; const int64_t b_end = seg_first + seg_count;
+			while (b0 < b_end) {
+				int64_t len = seg_batch;
+				if (guided > 0) {
+					const int64_t g = (int64_t)((double)(b_end - b0) / (guided * nworkers)) + 1;
+					len = std::max<int64_t>(std::min<int64_t>(64, seg_batch), std::min<int64_t>(seg_batch, g));
+				}
+				len = std::min(len, b_end - b0);
+				chunks.push_back({ b0, b0 + len });
+				b0 += len;
+			}
+		}
 		nworkers = (int)std::min<size_t>((size_t)nworkers, chunks.size());
 		// worker 0 is this engine; the others are lazily created engines on the same device sharing the query
 		while ((int)E->workers.size() < nworkers - 1) {
@@ -1370,8 +1400,11 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 			}
 			(void)hipStreamSynchronize(ws[wi]->st);
 		};
+		if (g_prof.on) fprintf(stderr, "[fasim prof] scan head (setup before the workers start)  %.3f s\n", now_s() - t_begin);
+		const double t_workers = now_s();
 		if (ws.size() == 1) run(0);
 		else { std::vector<std::thread> th; for (size_t wi = 0; wi < ws.size(); wi++) th.emplace_back(run, wi); for (auto& t : th) t.join(); }
+		if (g_prof.on) fprintf(stderr, "[fasim prof] scan workers                                  %.3f s\n", now_s() - t_workers);
 		for (size_t wi = 0; wi < ws.size(); wi++) if (wrc[wi]) { if (ws[wi] != E) E->err = ws[wi]->err; return wrc[wi]; }
 		for (auto& v : per_chunk) for (HostTriplex& t : v) all.push_back(std::move(t));
 		for (size_t wi = 0; wi < ws.size(); wi++) {

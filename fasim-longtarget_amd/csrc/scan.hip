@@ -100,28 +100,52 @@ __device__ __forceinline__ void lane_rows(int v, int seg_len, int vs, int* row0,
 	*row0 = s * seg_len + j * q + (j < rem ? j : rem);
 }
 
-template <int RP>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_scan(ScanArgs a)
+// score of target code t against the r-th row of global virtual lane v (doubled: bit 0 is the taint bit)
+__device__ __forceinline__ int scan_cell_score(const ScanArgs& a, int t, int v, int r)
 {
-	__shared__ __align__(16) uint8_t prof[5 * SCAN_CODE_STRIDE];
+	int row0, rows_v;
+	lane_rows(v, a.seg_len16, a.vs, &row0, &rows_v);
+	if (r >= rows_v) return SCAN_DEAD;
+	const int row = row0 + r;
+	if (row < a.m) return 2 * a.score[t * 5 + a.qcodes[row]];
+	return 0;                                 // rows [m, 16*segLen) are the reference's zero-score pad rows (Q3)
+}
+
+constexpr int PAIR_LANE_STRIDE = 96;          // bytes: 24 rows x {lo, hi} int16; 24 dwords keep 8 consecutive lanes' b128 reads on distinct banks
+constexpr int PAIR_STRIDE = 64 * PAIR_LANE_STRIDE;   // 6144 B per (code of half lo, code of half hi)
+constexpr int PAIR_LDS = 25 * PAIR_STRIDE;    // 153 600 B: one 1024-thread workgroup per CU
+
+// PAIR = false: 256-thread workgroups, per-code int16 profile (35 KB), the two halves of a lane fetch their own code's
+//               rows and a v_perm_b32 per row merges them;
+// PAIR = true : 1024-thread workgroups (16 waves = the whole CU), profile stored per PAIR of codes already merged
+//               (25 pairs x 64 lanes x 24 rows x 4 B = 150 KB of the 160 KB LDS): one VALU op per row less.
+template <int RP, bool PAIR>
+__global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_scan(ScanArgs a)
+{
+	extern __shared__ __align__(16) uint8_t prof[];
 	const int lane = threadIdx.x & 63;
 
-	// ---- stage the int16 profile: prof[t][lane][half][r] -------------------------------------------
-	for (int idx = threadIdx.x; idx < 5 * 128 * SCAN_RS; idx += blockDim.x) {
-		const int r = idx % SCAN_RS;
-		const int v = (idx / SCAN_RS) % 128;
-		const int t = idx / (SCAN_RS * 128);
+	if constexpr (PAIR) {
+		// ---- prof[t_lo * 5 + t_hi][lane][r] = { score(t_lo, row r of virtual lane 2*lane), score(t_hi, ... 2*lane+1) }
+		for (int idx = threadIdx.x; idx < 25 * 64 * 24; idx += blockDim.x) {
+			const int r = idx % 24;
+			const int l = (idx / 24) % 64;
+			const int pr = idx / (24 * 64);
+			const int lo = scan_cell_score(a, pr / 5, 128 * a.tile + 2 * l, r);
+			const int hi = scan_cell_score(a, pr % 5, 128 * a.tile + 2 * l + 1, r);
+			*reinterpret_cast<uint32_t*>(prof + pr * PAIR_STRIDE + l * PAIR_LANE_STRIDE + r * 4) = ((uint32_t)(uint16_t)(int16_t)lo) | ((uint32_t)(uint16_t)(int16_t)hi << 16);
+		}
+	} else {
+		// ---- stage the int16 profile: prof[t][lane][half][r] -------------------------------------------
 		// stripe-aligned layout: the reference's stripe s = rows [s*segLen, (s+1)*segLen) is spread over `vs` virtual
 		// lanes, so every stripe boundary is a virtual-lane boundary; this launch stages the rows of its tile only
-		int row0, rows_v;
-		lane_rows(128 * a.tile + v, a.seg_len16, a.vs, &row0, &rows_v);
-		const int row = row0 + r;
-		int sc = SCAN_DEAD;
-		if (r < rows_v) {
-			if (row < a.m) sc = 2 * a.score[t * 5 + a.qcodes[row]];       // doubled: bit 0 is the taint bit
-			else sc = 0;                      // rows [m, 16*segLen) are the reference's zero-score pad rows (Q3)
+		for (int idx = threadIdx.x; idx < 5 * 128 * SCAN_RS; idx += blockDim.x) {
+			const int r = idx % SCAN_RS;
+			const int v = (idx / SCAN_RS) % 128;
+			const int t = idx / (SCAN_RS * 128);
+			const int sc = scan_cell_score(a, t, 128 * a.tile + v, r);
+			*reinterpret_cast<int16_t*>(prof + t * SCAN_CODE_STRIDE + (v >> 1) * SCAN_LANE_STRIDE + (v & 1) * 48 + r * 2) = (int16_t)sc;
 		}
-		*reinterpret_cast<int16_t*>(prof + t * SCAN_CODE_STRIDE + (v >> 1) * SCAN_LANE_STRIDE + (v & 1) * 48 + r * 2) = (int16_t)sc;
 	}
 	__syncthreads();
 
@@ -143,7 +167,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 	const v2u startm = __builtin_bit_cast(v2u, startbits);
 	// the refined test needs F to die inside one stripe (F <= 234 decays by 4 per row)
 	const bool lvl2 = a.seg_len16 >= 96 && !a.coarse;
-	const uint8_t* pl = prof + lane * SCAN_LANE_STRIDE;
+	const uint8_t* pl = prof + lane * (PAIR ? PAIR_LANE_STRIDE : SCAN_LANE_STRIDE);
 
 	for (;;) {
 		int w = 0;
@@ -188,21 +212,25 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 			const int recv_cm = vshift(cm, in_cm);
 			const int recv_fp = vshift(fpo, in_fp);
 			const int t_lo = tc & 0xff, t_hi = (tc >> 16) & 0xff;
-			const uint8_t* pa = pl + t_lo * SCAN_CODE_STRIDE;
-			const uint8_t* pb = pl + t_hi * SCAN_CODE_STRIDE + 48;
+			const uint8_t* pa = PAIR ? pl + (t_lo * 5 + t_hi) * PAIR_STRIDE : pl + t_lo * SCAN_CODE_STRIDE;
+			const uint8_t* pb = pl + t_hi * SCAN_CODE_STRIDE + 48;      // (!PAIR only)
 			int hprev = recv_h_last;                  // H[i0-1][c-1]
 			recv_h_last = recv_h;
 			v2u f = __builtin_bit_cast(v2u, recv_f);
 			v2s lmax = (v2s){ 0, 0 };
+			constexpr int ROWS_PER_LOAD = PAIR ? 4 : 8;
 #pragma unroll
-			for (int g = 0; g < (RP + 7) / 8; g++) {
+			for (int g = 0; g < (RP + ROWS_PER_LOAD - 1) / ROWS_PER_LOAD; g++) {
 				const v4i A = *reinterpret_cast<const v4i*>(pa + 16 * g);
-				const v4i B = *reinterpret_cast<const v4i*>(pb + 16 * g);
+				v4i B = A;
+				if constexpr (!PAIR) B = *reinterpret_cast<const v4i*>(pb + 16 * g);
 #pragma unroll
-				for (int k = 0; k < 8; k++) {
-					const int r = 8 * g + k;
+				for (int k = 0; k < ROWS_PER_LOAD; k++) {
+					const int r = ROWS_PER_LOAD * g + k;
 					if (r < RP) {
-						const int sc = __builtin_amdgcn_perm(B[k >> 1], A[k >> 1], (k & 1) ? 0x07060302 : 0x05040100);
+						int sc;
+						if constexpr (PAIR) sc = A[k];
+						else sc = __builtin_amdgcn_perm(B[k >> 1], A[k >> 1], (k & 1) ? 0x07060302 : 0x05040100);
 						const int hold = H[r];
 						v2s h = __builtin_elementwise_add_sat(s_from(hprev), s_from(sc));
 						h = __builtin_elementwise_max(h, s_from(E[r]));
@@ -283,20 +311,26 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 	}
 }
 
-template <int RP>
+template <int RP, bool PAIR>
 static hipError_t launch_scan_t(const ScanArgs& a, hipStream_t st)
 {
 	hipError_t err = hipMemsetAsync(a.counter, 0, sizeof(uint32_t), st);
 	if (err != hipSuccess) return err;
-	long waves = a.nwork;
 	// Short-lived workgroups (each wave takes about `per_wave` units from the queue) instead of a persistent grid: slots
 	// free up every few milliseconds, so the latency-bound kernels of the other batches in flight get dispatched at once
 	// instead of waiting for this kernel to drain.  FASIM_GRID_UNITS=0 restores the persistent grid.
 	static const int per_wave = [] { const char* e = getenv("FASIM_GRID_UNITS"); return e ? atoi(e) : 2; }();
-	long blocks = (waves + 3) / 4;
-	if (per_wave > 0) blocks = (waves + 4 * per_wave - 1) / (4 * per_wave);
-	else if (blocks > 256 * 4) blocks = 256 * 4;
-	hipLaunchKernelGGL(k_scan<RP>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+	constexpr int WPB = PAIR ? 16 : 4;                   // waves per workgroup
+	const long waves = a.nwork;
+	long blocks = (waves + WPB - 1) / WPB;
+	if (per_wave > 0) blocks = (waves + WPB * per_wave - 1) / (WPB * per_wave);
+	else if (blocks > 256 * 16 / WPB) blocks = 256 * 16 / WPB;
+	const size_t lds = PAIR ? (size_t)PAIR_LDS : (size_t)5 * SCAN_CODE_STRIDE;
+	if (PAIR) {
+		static bool attr_set = false;                   // (benign race: the call is idempotent)
+		if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_scan<RP, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+	}
+	hipLaunchKernelGGL((k_scan<RP, PAIR>), dim3((unsigned)blocks), dim3(PAIR ? 1024 : 256), lds, st, a);
 	return hipGetLastError();
 }
 
@@ -320,11 +354,12 @@ hipError_t launch_scan(const ScanLaunch& L, hipStream_t st)
 	// RP must be exactly ceil(segLen/vs): every virtual lane then owns RP or RP-1 rows.  One launch per tile of 128
 	// virtual lanes (long queries): tile t reads the bottom row tile t-1 left in `boundary` and overwrites it in place.
 	const int rp = (a.seg_len16 + a.vs - 1) / a.vs;
+	static const bool pair = [] { const char* e = getenv("FASIM_SCAN_PAIR"); return e ? atoi(e) != 0 : true; }();
 	for (int t = 0; t < a.ntiles; t++) {
 		a.tile = t;
 		hipError_t err = hipErrorInvalidValue;
 		switch (rp) {
-#define FASIM_SCAN_CASE(N) case N: err = launch_scan_t<N>(a, st); break;
+#define FASIM_SCAN_CASE(N) case N: err = pair ? launch_scan_t<N, true>(a, st) : launch_scan_t<N, false>(a, st); break;
 		FASIM_SCAN_CASE(1) FASIM_SCAN_CASE(2) FASIM_SCAN_CASE(3) FASIM_SCAN_CASE(4) FASIM_SCAN_CASE(5) FASIM_SCAN_CASE(6)
 		FASIM_SCAN_CASE(7) FASIM_SCAN_CASE(8) FASIM_SCAN_CASE(9) FASIM_SCAN_CASE(10) FASIM_SCAN_CASE(11) FASIM_SCAN_CASE(12)
 		FASIM_SCAN_CASE(13) FASIM_SCAN_CASE(14) FASIM_SCAN_CASE(15) FASIM_SCAN_CASE(16) FASIM_SCAN_CASE(17) FASIM_SCAN_CASE(18)
