@@ -162,6 +162,28 @@ def test_long_queries_scan(mod, engine, golden_dir, name):
     assert mod.tfosorted(res, chro, start, p) == open(os.path.join(golden_dir, name + ".TFOsorted"), "rb").read()
 
 
+def test_stage1_score_saturating_the_doubled_lanes(mod, golden_dir):
+    """Stage-1 score 19 905 > 16 383: k_scan's doubled 16-bit lanes saturate, the unit must fall back to the 16-bit
+    stripe-faithful kernel for its score and to the hazard path for its column maxima (same records as the reference)."""
+    _, rna = synth.read_fasta(os.path.join(golden_dir, "satq.fa"))
+    hdr, dna = synth.read_fasta(os.path.join(golden_dir, "sat5k.fa"))
+    _, units = helpers.parse_scan(helpers.gunzip(os.path.join(golden_dir, "sat5k.scan.gz")))
+    assert max(u["stage1"] for u in units) > 16383
+    e = mod.Engine(0)
+    e.set_query(rna)
+    res = e.scan(dna, mod.default_params(cLength=20))
+    assert res.stats["candidates"] == sum(u["ncand"] for u in units)
+    assert res.triplexes() == _expected_triplexes(units)
+    assert res.stats["stage1_word_reruns"] >= 1 and res.stats["kernel_launches"][0] > 0
+    t, _ = mod.encode_unit(dna, max(units, key=lambda u: u["stage1"])["enc"])
+    assert e.calc_score_once(t) == max(u["stage1"] for u in units)
+    p = mod.default_params(cLength=40)
+    res = e.scan(dna, p)
+    _, chro, start = mod.parse_dna_header(hdr)
+    assert mod.tfosorted(res, chro, start, p) == open(os.path.join(golden_dir, "sat5k.TFOsorted"), "rb").read()
+    e.close()
+
+
 def test_systolic_and_stripe_faithful_paths_agree(mod, h19, golden_dir, monkeypatch):
     """FASIM_SCAN_V1 / FASIM_ALIGN_V1 force the stripe-faithful kernels everywhere; records must be identical."""
     _, dna = synth.read_fasta(os.path.join(golden_dir, "planted40k.fa"))

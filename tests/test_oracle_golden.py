@@ -122,3 +122,15 @@ def test_long_queries(oracle_build, golden_dir, name):
     assert out == helpers.gunzip(os.path.join(golden_dir, name + ".scan.gz"))
     out = helpers.oracle_cli(oracle_build, "tfosorted", rna, dna, "-lg", "40", "-threads", "8")
     assert out == open(os.path.join(golden_dir, name + ".TFOsorted"), "rb").read()
+
+
+def test_stage1_score_beyond_16383(oracle_build, golden_dir):
+    """A unit whose exact stage-1 score is 19 905 (only the 16-bit pass of calc_score_once can hold it)."""
+    rna, dna = os.path.join(golden_dir, "satq.fa"), os.path.join(golden_dir, "sat5k.fa")
+    out = helpers.oracle_cli(oracle_build, "scan", rna, dna, "-detail", "0", "-threads", "8")
+    gold = helpers.gunzip(os.path.join(golden_dir, "sat5k.scan.gz"))
+    assert out == gold
+    _, units = helpers.parse_scan(gold)
+    assert max(u["stage1"] for u in units) > 16383
+    out = helpers.oracle_cli(oracle_build, "tfosorted", rna, dna, "-lg", "40", "-threads", "8")
+    assert out == open(os.path.join(golden_dir, "sat5k.TFOsorted"), "rb").read()
