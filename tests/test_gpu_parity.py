@@ -162,6 +162,29 @@ def test_long_queries_scan(mod, engine, golden_dir, name):
     assert mod.tfosorted(res, chro, start, p) == open(os.path.join(golden_dir, name + ".TFOsorted"), "rb").read()
 
 
+@pytest.mark.parametrize("name,systolic", [("h19_700", True), ("h19_100", False)])
+def test_short_queries_scan(mod, golden_dir, name, systolic):
+    """700 nt: systolic kernels with the coarse Q2 test (stripes shorter than 96 rows); 100 nt: fewer than 8 rows per
+    stripe, everything runs on the stripe-faithful kernels."""
+    _, rna = synth.read_fasta(os.path.join(golden_dir, name + ".fa"))
+    hdr, dna = synth.read_fasta(os.path.join(golden_dir, name + "_dna.fa"))
+    _, units = helpers.parse_scan(helpers.gunzip(os.path.join(golden_dir, name + ".scan.gz")))
+    e = mod.Engine(0)
+    e.set_query(rna)
+    res = e.scan(dna, mod.default_params(cLength=20))
+    assert res.stats["candidates"] == sum(u["ncand"] for u in units)
+    assert res.triplexes() == _expected_triplexes(units)
+    if systolic:
+        assert res.stats["kernel_launches"][0] > 0
+    p = mod.default_params(cLength=25)
+    res = e.scan(dna, p)
+    _, chro, start = mod.parse_dna_header(hdr)
+    assert mod.tfosorted(res, chro, start, p) == open(os.path.join(golden_dir, name + ".TFOsorted"), "rb").read()
+    for level in (1, 2):
+        assert mod.tfoclass(res, level, chro, start, len(dna), name, p) == open(os.path.join(golden_dir, f"{name}.TFOclass{level}"), "rb").read()
+    e.close()
+
+
 def test_stage1_score_saturating_the_doubled_lanes(mod, golden_dir):
     """Stage-1 score 19 905 > 16 383: k_scan's doubled 16-bit lanes saturate, the unit must fall back to the 16-bit
     stripe-faithful kernel for its score and to the hazard path for its column maxima (same records as the reference)."""

@@ -134,3 +134,12 @@ def test_stage1_score_beyond_16383(oracle_build, golden_dir):
     assert max(u["stage1"] for u in units) > 16383
     out = helpers.oracle_cli(oracle_build, "tfosorted", rna, dna, "-lg", "40", "-threads", "8")
     assert out == open(os.path.join(golden_dir, "sat5k.TFOsorted"), "rb").read()
+
+
+@pytest.mark.parametrize("name", ["h19_700", "h19_100"])
+def test_short_queries(oracle_build, golden_dir, name):
+    rna, dna = os.path.join(golden_dir, name + ".fa"), os.path.join(golden_dir, name + "_dna.fa")
+    out = helpers.oracle_cli(oracle_build, "scan", rna, dna, "-detail", "0", "-threads", "8")
+    assert out == helpers.gunzip(os.path.join(golden_dir, name + ".scan.gz"))
+    out = helpers.oracle_cli(oracle_build, "tfosorted", rna, dna, "-lg", "25", "-threads", "8")
+    assert out == open(os.path.join(golden_dir, name + ".TFOsorted"), "rb").read()
