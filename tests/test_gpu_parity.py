@@ -162,6 +162,23 @@ def test_long_queries_scan(mod, engine, golden_dir, name):
     assert mod.tfosorted(res, chro, start, p) == open(os.path.join(golden_dir, name + ".TFOsorted"), "rb").read()
 
 
+def test_untidy_input_scan(mod, engine, h19, golden_dir):
+    """N runs (a skipped all-N segment; units with N take the separate stage-1 pass), lower case, IUPAC codes."""
+    hdr, dna = synth.read_fasta(os.path.join(golden_dir, "messy.fa"))
+    meta, units = helpers.parse_scan(helpers.gunzip(os.path.join(golden_dir, "messy.scan.gz")))
+    engine.set_query(h19)
+    res = engine.scan(dna, mod.default_params(cLength=20))
+    assert res.stats["segments_skipped"] == len(meta["skipped"]) > 0
+    assert res.stats["units"] == len(units)
+    assert res.stats["candidates"] == sum(u["ncand"] for u in units)
+    assert res.triplexes() == _expected_triplexes(units)
+    assert res.stats["stage1_word_reruns"] > 0, "units with N must have taken the separate stage-1 pass"
+    p = mod.default_params(cLength=30)
+    res = engine.scan(dna, p)
+    _, chro, start = mod.parse_dna_header(hdr)
+    assert mod.tfosorted(res, chro, start, p) == open(os.path.join(golden_dir, "messy.TFOsorted"), "rb").read()
+
+
 @pytest.mark.parametrize("name,systolic", [("h19_700", True), ("h19_100", False)])
 def test_short_queries_scan(mod, golden_dir, name, systolic):
     """700 nt: systolic kernels with the coarse Q2 test (stripes shorter than 96 rows); 100 nt: fewer than 8 rows per

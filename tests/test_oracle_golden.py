@@ -143,3 +143,15 @@ def test_short_queries(oracle_build, golden_dir, name):
     assert out == helpers.gunzip(os.path.join(golden_dir, name + ".scan.gz"))
     out = helpers.oracle_cli(oracle_build, "tfosorted", rna, dna, "-lg", "25", "-threads", "8")
     assert out == open(os.path.join(golden_dir, name + ".TFOsorted"), "rb").read()
+
+
+def test_untidy_input(oracle_build, golden_dir):
+    """N runs (one whole segment is skipped), lower-case letters and IUPAC codes in the DNA."""
+    rna, dna = os.path.join(golden_dir, "H19.fa"), os.path.join(golden_dir, "messy.fa")
+    out = helpers.oracle_cli(oracle_build, "scan", rna, dna, "-detail", "0", "-threads", "8")
+    gold = helpers.gunzip(os.path.join(golden_dir, "messy.scan.gz"))
+    assert out == gold
+    meta, _ = helpers.parse_scan(gold)
+    assert meta["skipped"], "fixture must contain a skipped all-N segment"
+    out = helpers.oracle_cli(oracle_build, "tfosorted", rna, dna, "-lg", "30", "-threads", "8")
+    assert out == open(os.path.join(golden_dir, "messy.TFOsorted"), "rb").read()
