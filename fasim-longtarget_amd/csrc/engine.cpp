@@ -860,7 +860,9 @@ int fasim_engine_create(int device, fasim_engine** out)
 	if (upload(E, E->enc_lut, lut.data(), lut.size()) || E->counter.ensure(64) != hipSuccess) { delete E; return FASIM_E_HIP; }
 	unsigned hc = std::thread::hardware_concurrency();
 	const char* env = getenv("FASIM_HOST_THREADS");
-	E->host_threads = env ? std::max(1, atoi(env)) : (int)std::min(32u, std::max(1u, hc));
+	// host side of a batch (CIGAR -> triplex record for every candidate alignment, ~1 us each): short bursts, shared by
+	// the batches in flight; 3/8 of the cores (96 on the 256-thread GPU hosts) keeps the burst of a batch below ~50 ms
+	E->host_threads = env ? std::max(1, atoi(env)) : (int)std::min(96u, std::max(1u, hc * 3 / 8));
 	E->host_threads_total = E->host_threads;
 	const char* v1 = getenv("FASIM_SCAN_V1");
 	E->scan_v1 = v1 && atoi(v1) != 0;
@@ -1280,10 +1282,23 @@ int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t*
 						AlignResult al = x.al; const int cut = x.cut;
 						if (al.sw_score == 0) continue;                                                    // fastsim.h:253
 						al.ref_begin += x.c.pos - cut + 1; al.ref_end += x.c.pos - cut + 1;                // :254-255
-						convert_triplex(al, cigars.data() + al.cigar_off, E->rna, seg, slen[s], enc, dna_start, p, mine, acgtn);
+						const size_t before = mine.size();
+						convert_triplex(al, cigars.data() + al.cigar_off, E->rna, seg, slen[s], enc, dna_start, p, mine, acgtn, false);
+						if (mine.size() > before) mine.back().cand = (int)k;
 					}
 					dedup_top(mine, p, per_unit[u]);
-					for (HostTriplex& t : per_unit[u]) { t.seg = (int)sidx[s]; t.enc = enc; }
+					std::vector<HostTriplex> one;
+					for (HostTriplex& t : per_unit[u]) {
+						t.seg = (int)sidx[s]; t.enc = enc;
+						if (!(t.score >= p.scoreMin && t.identity >= p.minIdentity && t.tri_score >= p.minStability && t.nt >= p.cLength)) continue;   // dropped below anyway
+						// the TFO / TTS strings of a surviving record: same conversion once more, this time keeping them
+						const CandState& x = cs[(size_t)t.cand];
+						AlignResult al = x.al;
+						al.ref_begin += x.c.pos - x.cut + 1; al.ref_end += x.c.pos - x.cut + 1;
+						one.clear();
+						convert_triplex(al, cigars.data() + al.cigar_off, E->rna, seg, slen[s], enc, dna_start, p, one, acgtn, true);
+						t.tfo.swap(one[0].tfo); t.tts.swap(one[0].tts);
+					}
 				}
 			};
 			const int nt = std::max(1, std::min(E->host_threads, B.nunit));

@@ -161,7 +161,7 @@ bool only_acgtn(const char* seg, int n)
 }
 
 void convert_triplex(const AlignResult& al, const uint32_t* cigar, const std::string& rna, const char* seg, int n, int enc,
-	long dna_start, const fasim_params& p, std::vector<HostTriplex>& list, bool seg_acgtn)
+	long dna_start, const fasim_params& p, std::vector<HostTriplex>& list, bool seg_acgtn, bool with_strings)
 {
 	const EncInfo e = enc_info(enc);
 	const char* o = kRuleOut[enc];
@@ -177,7 +177,9 @@ void convert_triplex(const AlignResult& al, const uint32_t* cigar, const std::st
 		return e.strand == 1 ? comp_letter(c) : c;
 	};
 	// expand the CIGAR from (ref_begin, query_begin): M -> (target, src, rna); I -> ('-','-',rna); D -> (target, src,'-')
-	std::string tgt_al, tts, tfo;
+	// (per-thread buffers: this runs for every candidate alignment, ~10^6 times per 2.5 Mb of DNA)
+	thread_local std::string tgt_al, tts, tfo;
+	tgt_al.clear(); tts.clear(); tfo.clear();
 	int q = al.ref_begin, r = al.query_begin;
 	for (int k = 0; k < al.cigar_len; k++) {
 		const uint32_t len = cigar[k] >> 4, op = cigar[k] & 0xf;
@@ -221,7 +223,7 @@ void convert_triplex(const AlignResult& al, const uint32_t* cigar, const std::st
 	t.starj = (int)(rs + dna_start); t.endj = (int)(re + dna_start);
 	t.strand = e.strand; t.reverse = e.para; t.rule = e.rule; t.nt = nt;
 	t.score = (float)al.sw_score; t.identity = identity; t.tri_score = tri;
-	t.tfo.swap(tfo); t.tts.swap(tts);
+	if (with_strings) { t.tfo = tfo; t.tts = tts; }
 	list.push_back(std::move(t));
 }
 

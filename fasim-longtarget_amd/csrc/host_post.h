@@ -35,13 +35,16 @@ struct HostTriplex {
 	float score, identity, tri_score;
 	std::string tfo, tts;
 	int seg = 0, enc = 0;
+	int cand = -1;                 // caller's index of the alignment this record came from (strings are filled in later)
 	int middle = 0, center = 0, motif = 0, neartriplex = 0;
 	long genomestart = 0, genomeend = 0;
 };
 
 // convertMyTriplex (fastsim.h:291-414): appends to `list` when nt >= ntMin
+// with_strings = false leaves tfo/tts empty (everything the dedup and the filters look at is numeric): the scan builds
+// the two strings only for the few records that survive them, by calling again with with_strings = true
 void convert_triplex(const AlignResult& al, const uint32_t* cigar, const std::string& rna, const char* seg, int n, int enc,
-	long dna_start, const fasim_params& p, std::vector<HostTriplex>& list, bool seg_acgtn);
+	long dna_start, const fasim_params& p, std::vector<HostTriplex>& list, bool seg_acgtn, bool with_strings = true);
 bool only_acgtn(const char* seg, int n);
 // tail of fastSIM (fastsim.h:273-288): sort/unique/sort/unique/sort, top 50, identity/stability/nt filter
 void dedup_top(std::vector<HostTriplex>& mine, const fasim_params& p, std::vector<HostTriplex>& out);
