@@ -168,6 +168,14 @@ struct UnitBatch {
 	std::vector<int> unit_len;      // columns per unit
 };
 
+// H2D copy without the trailing synchronisation: the caller keeps `src` alive until its next stream synchronisation
+int upload_async(fasim_engine* E, DevBuf& b, const void* src, size_t bytes)
+{
+	HIPOK(b.ensure(bytes ? bytes : 1));
+	if (bytes) HIPOK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, E->st));
+	return FASIM_OK;
+}
+
 int upload(fasim_engine* E, DevBuf& b, const void* src, size_t bytes)
 {
 	HIPOK(b.ensure(bytes ? bytes : 1));
@@ -592,8 +600,8 @@ int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& 
 	for (int k = 0; k < n; k += per_task) tasks.push_back(k);
 	tasks.push_back(n);
 	double tp = now_s();
-	int rc = upload(E, E->fprobs, probs.data(), sizeof(FwdProb) * n); if (rc) return rc;
-	rc = upload(E, E->ftasks, tasks.data(), sizeof(int32_t) * tasks.size()); if (rc) return rc;
+	int rc = upload_async(E, E->fprobs, probs.data(), sizeof(FwdProb) * n); if (rc) return rc;      // (both vectors outlive the
+	rc = upload(E, E->ftasks, tasks.data(), sizeof(int32_t) * tasks.size()); if (rc) return rc;          //  synchronisation in here)
 	g_prof.add(1, "run_fwd upload", now_s() - tp);
 	HIPOK(E->fstream.ensure((size_t)off + 256));
 	HIPOK(E->fout.ensure(sizeof(FwdOut) * n));
@@ -681,22 +689,22 @@ int run_finish(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb
 	std::vector<FwdProb> probs(n);
 	for (int k = 0; k < n; k++) { probs[k].tbase = (int64_t)W[k].unit * B.tstride + W[k].t0; probs[k].len = W[k].len; probs[k].stream_off = 0; }
 	const int scratch_cap = 16384;
-	int rc = upload(E, E->fprobs, probs.data(), sizeof(FwdProb) * n); if (rc) return rc;
-	rc = upload(E, E->fout, fo.data(), sizeof(FwdOut) * n); if (rc) return rc;
+	int rc = upload_async(E, E->fprobs, probs.data(), sizeof(FwdProb) * n); if (rc) return rc;      // (probs, fo and order outlive the
+	rc = upload_async(E, E->fout, fo.data(), sizeof(FwdOut) * n); if (rc) return rc;                 //  first synchronisation below)
 	HIPOK(E->aout.ensure(sizeof(AlignOutDev) * n));
 	const size_t pool_cap = (size_t)n * 12 + 4096;
 	HIPOK(E->cigpool.ensure(pool_cap * sizeof(uint32_t)));
 	HIPOK(E->cigcount.ensure(64));
 	hipError_t he;
+	std::vector<int32_t> order(n);
 	{
 		// process alignments grouped by score (a proxy for their size): the 64 threads of a wave then run DPs of similar
 		// length instead of all waiting for the largest one
-		std::vector<int32_t> order(n);
 		std::vector<int32_t> cnt(1026, 0);
 		for (int k = 0; k < n; k++) cnt[std::min(1024, std::max(0, fo[k].score)) + 1]++;
 		for (int b = 1; b < 1026; b++) cnt[b] += cnt[b - 1];
 		for (int k = 0; k < n; k++) order[cnt[std::min(1024, std::max(0, fo[k].score))]++] = k;
-		rc = upload(E, E->forder, order.data(), sizeof(int32_t) * n); if (rc) return rc;
+		rc = upload_async(E, E->forder, order.data(), sizeof(int32_t) * n); if (rc) return rc;
 	}
 	HIPOK(E->scratch.ensure((size_t)((n + 63) / 64) * 64 * 2048));
 	{ TimedScope ts(E, 3);
@@ -707,6 +715,7 @@ int run_finish(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb
 	std::vector<AlignOutDev> ao(n);
 	uint32_t pool_used = 0;
 	HIPOK(hipMemcpyAsync(ao.data(), E->aout.p, sizeof(AlignOutDev) * n, hipMemcpyDeviceToHost, E->st));
+	HIPOK(hipMemcpyAsync(&pool_used, E->cigcount.p, sizeof pool_used, hipMemcpyDeviceToHost, E->st));
 	HIPOK(hipStreamSynchronize(E->st));
 	{
 		// alignments whose band / direction matrix did not fit the LDS kernel: same algorithm on global scratch, first
@@ -725,11 +734,10 @@ int run_finish(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb
 				E->cigpool.as<uint32_t>(), (uint32_t)pool_cap, E->cigcount.as<uint32_t>(), E->st); }
 			if (he != hipSuccess) return fail(E, FASIM_E_HIP, "finish (global scratch) launch failed: %s", hipGetErrorString(he));
 			HIPOK(hipMemcpyAsync(ao.data(), E->aout.p, sizeof(AlignOutDev) * n, hipMemcpyDeviceToHost, E->st));
+			HIPOK(hipMemcpyAsync(&pool_used, E->cigcount.p, sizeof pool_used, hipMemcpyDeviceToHost, E->st));
 			HIPOK(hipStreamSynchronize(E->st));
 		}
 	}
-	HIPOK(hipMemcpyAsync(&pool_used, E->cigcount.p, sizeof pool_used, hipMemcpyDeviceToHost, E->st));
-	HIPOK(hipStreamSynchronize(E->st));
 	if (pool_used > pool_cap) pool_used = (uint32_t)pool_cap;
 	const uint32_t pool_base = (uint32_t)cigars.size();
 	cigars.resize((size_t)pool_base + pool_used);
@@ -1161,12 +1169,24 @@ int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t*
 		std::vector<CandState> cs;
 		{
 			ProfScope ps(7, "pick candidates");
-			std::vector<Cand> tmp;
-			for (int u = 0; u < B.nunit; u++) {
-				pick_candidates(hits.data() + hoff[u], hcnt[u], tmp);
-				for (const Cand& c : tmp) { CandState x; memset(&x.fsel, 0, sizeof x.fsel); memset(&x.fbest, 0, sizeof x.fbest);
-					x.unit = u; x.c = c; x.done = 0; x.cut = 0; x.bestcut = 0; x.flag = 0; x.exact = 0; cs.push_back(x); }
-			}
+			// contiguous unit ranges on the host threads, concatenated in unit order
+			const int nt = std::max(1, std::min(E->host_threads, B.nunit / 256));
+			std::vector<std::vector<CandState>> part(nt);
+			auto work = [&](int ti) {
+				std::vector<Cand> tmp;
+				const int u0 = (int)((int64_t)B.nunit * ti / nt), u1 = (int)((int64_t)B.nunit * (ti + 1) / nt);
+				for (int u = u0; u < u1; u++) {
+					pick_candidates(hits.data() + hoff[u], hcnt[u], tmp);
+					for (const Cand& c : tmp) { CandState x; memset(&x.fsel, 0, sizeof x.fsel); memset(&x.fbest, 0, sizeof x.fbest);
+						x.unit = u; x.c = c; x.done = 0; x.cut = 0; x.bestcut = 0; x.flag = 0; x.exact = 0; part[ti].push_back(x); }
+				}
+			};
+			if (nt == 1) work(0);
+			else { std::vector<std::thread> th; for (int k = 0; k < nt; k++) th.emplace_back(work, k); for (auto& t : th) t.join(); }
+			size_t total = 0;
+			for (auto& v : part) total += v.size();
+			cs.reserve(total);
+			for (auto& v : part) cs.insert(cs.end(), v.begin(), v.end());
 		}
 		st.candidates += (int64_t)cs.size();
 		bool v2 = true;
@@ -1232,6 +1252,30 @@ int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t*
 			std::vector<int> ex;
 			for (size_t k = 0; k < cs.size(); k++) if (!v2 || cs[k].exact) { ex.push_back((int)k); cs[k].done = 0; cs[k].flag = 0; cs[k].best = AlignResult(); cs[k].al = AlignResult(); }
 			if (v2) st.exact_replays += (int64_t)ex.size();
+			if (v2) {
+				// few candidates (of the order of 10^-5): all four window tries of each in ONE pass over the stripe-faithful
+				// path (the windows depend only on the candidate's score and position, fastsim.h:209-211), then the
+				// accept / best / last rule of fastsim.h:218-250 over the results in try order
+				std::vector<WindowProb> W; std::vector<int> who, cuts;
+				for (int k : ex) {
+					for (int it = 0; it < 4; it++) {
+						int cut;
+						if (!window_for_try(it, cs[k].c.score, cs[k].c.pos, &cut)) break;
+						W.push_back({ cs[k].unit, cs[k].c.pos - cut + 1, cut }); who.push_back(k); cuts.push_back(cut);
+					}
+				}
+				if (!W.empty()) {
+					std::vector<AlignResult> res;
+					rc = run_align(E, B, W, res, cigars, nullptr); if (rc) return rc;
+					for (size_t i = 0; i < who.size(); i++) {
+						CandState& x = cs[who[i]];
+						if (x.done) continue;
+						x.al = res[i]; x.cut = cuts[i];
+						if (x.al.sw_score >= x.c.score) { x.flag = 1; x.done = 1; continue; }
+						if (x.al.sw_score > x.best.sw_score && x.al.ref_end == x.cut - 1) { x.best = x.al; x.bestcut = x.cut; x.flag = 2; }
+					}
+				}
+			} else
 			for (int it = 0; it < 4 && !ex.empty(); it++) {
 				std::vector<WindowProb> W; std::vector<int> who;
 				for (int k : ex) {
@@ -1243,7 +1287,7 @@ int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t*
 					who.push_back(k);
 				}
 				if (W.empty()) break;
-				if (!v2) { st.align_calls += (int64_t)W.size(); for (const WindowProb& w : W) st.cells_stage3 += (int64_t)E->m * w.len; }
+				st.align_calls += (int64_t)W.size(); for (const WindowProb& w : W) st.cells_stage3 += (int64_t)E->m * w.len;
 				std::vector<AlignResult> res;
 				rc = run_align(E, B, W, res, cigars, nullptr); if (rc) return rc;
 				for (size_t i = 0; i < who.size(); i++) {
