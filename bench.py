@@ -34,7 +34,12 @@ import __graft_entry__ as entry  # noqa: E402
 import synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
-VALU_PEAK_TOPS = 78.6           # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, one 32-bit integer op per lane per clock
+VALU_PEAK_TOPS = 78.6           # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz: plain VALU, one lane-instruction per lane per clock
+# The DP kernels consist of packed 16-bit ops (v_pk_add_i16 / v_pk_max_* / v_pk_sub_u16).  Measured with
+# rocprofv3 --pmc on k_scan and k_align_fwd (profiles/r01_sq_counters.txt): SQ_INSTS_VALU == SQ_BUSY_CU_CYCLES, i.e. one
+# wave64 VALU instruction per CU clock = 4 clocks per instruction and SIMD with four waves resident: the packed ops
+# issue at half the plain rate, and at that rate the kernels sit at the issue limit.
+VALU_PK16_PEAK_TOPS = 39.3      # 256 CU x 4 SIMD x 16 lanes x 2.4 GHz (lane-instructions/s of packed 16-bit ops)
 KERNEL_NAMES = ["k_scan (fused stage 1+2)", "k_striped<PRE|MAX1> (stage 1/2 hazard re-runs)", "k_align_fwd (stage 3 forward)",
                 "k_finish_lds (reverse pass + traceback)", "k_encode/k_scan_post/k_hits/k_build_stream",
                 "k_striped<ALIGN|REV> (stage 3 exact replays)", "k_finish/k_banded (global scratch)", "-"]
@@ -196,7 +201,7 @@ def main():
         dom = 0
         launches = max(1, agg["kernel_launches"][dom])
         avg_ms = kms[dom] / launches
-        cells_dom, ops_per_cell = agg["cells_stage2"], 5.0
+        cells_dom, ops_per_cell = agg["cells_stage2"], 4.5
         traffic_per_unit = pmc.get("k_scan", {}).get("hbm_bytes_per_unit")
         out = {
             "metric": "SW Gcells/s (logical, whole job: stage 1+2+3 of the triplex scan)",
@@ -225,10 +230,11 @@ def main():
             "roofline_stage3": kernel_roofline(2),
             "valu": {"kernel": KERNEL_NAMES[dom], "gcells_per_s": round(cells_dom / (kms[dom] * 1e-3) / 1e9, 2),
                      "ops_per_cell": ops_per_cell, "achieved_tops": round(cells_dom * ops_per_cell / (kms[dom] * 1e-3) / 1e12, 3),
-                     "peak_tops": VALU_PEAK_TOPS,
-                     "frac": round(cells_dom * ops_per_cell / (kms[dom] * 1e-3) / 1e12 / VALU_PEAK_TOPS, 4),
+                     "peak_tops": VALU_PK16_PEAK_TOPS,
+                     "frac": round(cells_dom * ops_per_cell / (kms[dom] * 1e-3) / 1e12 / VALU_PK16_PEAK_TOPS, 4),
                      "note": "VALU instructions per DP cell x executed cells / HIP-event time of this kernel family; "
-                             "peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (one VALU instruction per lane per clock; the "
+                             "peak = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz: packed 16-bit VALU ops issue at 4 clocks per wave64 (measured, "
+                             "profiles/r01_sq_counters.txt), half the plain VALU rate; the "
                              "packed 16-bit kernels process two cells per lane-instruction); kernel times include "
                              "sharing the GPU with the other batches in flight"},
         }
@@ -237,10 +243,10 @@ def main():
             "what": f"untimed pass over the first {iso['segments']} segments with ONE batch in flight (kernels run alone)",
             "units": iso["units"], "align_calls": iso["align_calls"],
             "k_scan": {"ms": round(ik[0], 2), "gcells_per_s": round(iso["cells_stage2"] / (ik[0] * 1e-3) / 1e9, 1),
-                       "valu_frac": round(iso["cells_stage2"] * 5.0 / (ik[0] * 1e-3) / 1e12 / VALU_PEAK_TOPS, 4),
+                       "valu_frac": round(iso["cells_stage2"] * 4.5 / (ik[0] * 1e-3) / 1e12 / VALU_PK16_PEAK_TOPS, 4),
                        "hbm_GBps": round((traffic_per_unit or 0) * iso["units"] / (ik[0] * 1e-3) / 1e9, 2)},
             "k_align_fwd": {"ms": round(ik[2], 2), "gcells_per_s": round(iso["align_calls"] and iso["cells_stage3"] / (ik[2] * 1e-3) / 1e9, 1),
-                            "valu_frac": round(iso["cells_stage3"] * 5.5 / (ik[2] * 1e-3) / 1e12 / VALU_PEAK_TOPS, 4)},
+                            "valu_frac": round(iso["cells_stage3"] * 5.5 / (ik[2] * 1e-3) / 1e12 / VALU_PK16_PEAK_TOPS, 4)},
             "k_striped_hazard_reruns_ms": round(ik[1], 2), "k_finish_lds_ms": round(ik[3], 2),
             "k_striped_exact_replays_ms": round(ik[5], 2), "k_finish_k_banded_global_ms": round(ik[6], 2),
         }

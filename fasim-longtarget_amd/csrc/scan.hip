@@ -64,6 +64,10 @@ __device__ __forceinline__ v2u pk_ksubs(uint32_t k, v2u a) { v2u r; asm("v_pk_su
 __device__ __forceinline__ v2u pk_minu(v2u a, v2u b) { v2u r; asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ v2u pk_minu_k(v2u a, uint32_t k) { v2u r; asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "s"(k)); return r; }
 __device__ __forceinline__ v2u pk_maxu(v2u a, v2u b) { v2u r; asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// x |= bits with input and output tied to ONE register: a value that the rare branch may modify then needs no copy at
+// the join with the common path (plain C would let the allocator put the two versions into different registers and
+// pay a v_mov per row in every step)
+__device__ __forceinline__ void or_in_place(int& x, int bits) { asm volatile("v_or_b32 %0, %0, %1" : "+v"(x) : "v"(bits)); }
 
 constexpr int SCAN_RS = 24;                 // storage rows per virtual lane in the LDS profile
 constexpr int SCAN_LANE_STRIDE = 112;       // bytes: 2 halves x 24 rows x 2 B + 16 B pad (bank-conflict-free b128)
@@ -111,9 +115,15 @@ __device__ __forceinline__ int scan_cell_score(const ScanArgs& a, int t, int v, 
 	return 0;                                 // rows [m, 16*segLen) are the reference's zero-score pad rows (Q3)
 }
 
-constexpr int PAIR_LANE_STRIDE = 96;          // bytes: 24 rows x {lo, hi} int16; 24 dwords keep 8 consecutive lanes' b128 reads on distinct banks
-constexpr int PAIR_STRIDE = 64 * PAIR_LANE_STRIDE;   // 6144 B per (code of half lo, code of half hi)
-constexpr int PAIR_LDS = 25 * PAIR_STRIDE;    // 153 600 B: one 1024-thread workgroup per CU
+// 24 rows x {lo, hi} int16 = 96 B per lane.  A ds_read_b128 serves 16 lanes per pass; with a plain 96-B (24-dword) lane
+// stride lanes l and l+8 start on the same bank (measured: SQ_LDS_BANK_CONFLICT = 4 cycles per read), so every group
+// of 8 lanes is skewed by 16 B more: lane offset = (lane >> 3) * 784 + (lane & 7) * 96, all 16 windows distinct.
+constexpr int PAIR_LANE_STRIDE = 96;
+constexpr int PAIR_GROUP_STRIDE = 8 * PAIR_LANE_STRIDE + 16;   // 784 B
+constexpr int PAIR_STRIDE = 6400;             // >= 8 * 784 B per (code of half lo, code of half hi); a multiple of the 256-B bank row,
+                                              // so that lanes holding different pairs keep their bank pattern
+constexpr int PAIR_LDS = 25 * PAIR_STRIDE;    // 160 000 B of the 163 840: one 1024-thread workgroup per CU
+__device__ __forceinline__ int pair_lane_offset(int lane) { return (lane >> 3) * PAIR_GROUP_STRIDE + (lane & 7) * PAIR_LANE_STRIDE; }
 
 // PAIR = false: 256-thread workgroups, per-code int16 profile (35 KB), the two halves of a lane fetch their own code's
 //               rows and a v_perm_b32 per row merges them;
@@ -133,7 +143,7 @@ __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves
 			const int pr = idx / (24 * 64);
 			const int lo = scan_cell_score(a, pr / 5, 128 * a.tile + 2 * l, r);
 			const int hi = scan_cell_score(a, pr % 5, 128 * a.tile + 2 * l + 1, r);
-			*reinterpret_cast<uint32_t*>(prof + pr * PAIR_STRIDE + l * PAIR_LANE_STRIDE + r * 4) = ((uint32_t)(uint16_t)(int16_t)lo) | ((uint32_t)(uint16_t)(int16_t)hi << 16);
+			*reinterpret_cast<uint32_t*>(prof + pr * PAIR_STRIDE + pair_lane_offset(l) + r * 4) = ((uint32_t)(uint16_t)(int16_t)lo) | ((uint32_t)(uint16_t)(int16_t)hi << 16);
 		}
 	} else {
 		// ---- stage the int16 profile: prof[t][lane][half][r] -------------------------------------------
@@ -167,7 +177,7 @@ __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves
 	const v2u startm = __builtin_bit_cast(v2u, startbits);
 	// the refined test needs F to die inside one stripe (F <= 234 decays by 4 per row)
 	const bool lvl2 = a.seg_len16 >= 96 && !a.coarse;
-	const uint8_t* pl = prof + lane * (PAIR ? PAIR_LANE_STRIDE : SCAN_LANE_STRIDE);
+	const uint8_t* pl = prof + (PAIR ? pair_lane_offset(lane) : lane * SCAN_LANE_STRIDE);
 
 	for (;;) {
 		int w = 0;
@@ -192,7 +202,11 @@ __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves
 		v2u hzacc = (v2u){ 0, 0 };      // != 0: the unit goes to the stripe-faithful kernel (coarse test of short queries)
 		int chunk = CODE_N;
 		const int nsteps = n + 127;
-		for (int step = 0; step < nsteps; step++) {
+		// The step body is instantiated twice per loop iteration: within one step the new H column is written into the
+		// registers the profile rows were loaded into (the old H column is still being read), so consecutive steps
+		// alternate between two register banks; with a single copy of the body the compiler has to move the whole column
+		// back at the end of every step (~16 v_mov_b64 of ~230 instructions).
+		auto do_step = [&](const int step) __attribute__((always_inline)) {
 			if ((step & 63) == 0) {
 				const int c = step + lane;
 				chunk = c < n ? (int)tc_unit[c] : CODE_N;
@@ -214,45 +228,59 @@ __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves
 			const int t_lo = tc & 0xff, t_hi = (tc >> 16) & 0xff;
 			const uint8_t* pa = PAIR ? pl + (t_lo * 5 + t_hi) * PAIR_STRIDE : pl + t_lo * SCAN_CODE_STRIDE;
 			const uint8_t* pb = pl + t_hi * SCAN_CODE_STRIDE + 48;      // (!PAIR only)
-			int hprev = recv_h_last;                  // H[i0-1][c-1]
+			const int hdiag0 = recv_h_last;           // H[i0-1][c-1]
 			recv_h_last = recv_h;
 			v2u f = __builtin_bit_cast(v2u, recv_f);
-			v2s lmax = (v2s){ 0, 0 };
+			v2s lmx[4] = { (v2s){ 0, 0 }, (v2s){ 0, 0 }, (v2s){ 0, 0 }, (v2s){ 0, 0 } };   // independent chains: no back-to-back dependent v_pk_max
 			constexpr int ROWS_PER_LOAD = PAIR ? 4 : 8;
+			constexpr int NLOAD = (RP + ROWS_PER_LOAD - 1) / ROWS_PER_LOAD;
+			v4i PA[NLOAD], PB[NLOAD];
 #pragma unroll
-			for (int g = 0; g < (RP + ROWS_PER_LOAD - 1) / ROWS_PER_LOAD; g++) {
-				const v4i A = *reinterpret_cast<const v4i*>(pa + 16 * g);
-				v4i B = A;
-				if constexpr (!PAIR) B = *reinterpret_cast<const v4i*>(pb + 16 * g);
-#pragma unroll
-				for (int k = 0; k < ROWS_PER_LOAD; k++) {
-					const int r = ROWS_PER_LOAD * g + k;
-					if (r < RP) {
-						int sc;
-						if constexpr (PAIR) sc = A[k];
-						else sc = __builtin_amdgcn_perm(B[k >> 1], A[k >> 1], (k & 1) ? 0x07060302 : 0x05040100);
-						const int hold = H[r];
-						v2s h = __builtin_elementwise_add_sat(s_from(hprev), s_from(sc));
-						h = __builtin_elementwise_max(h, s_from(E[r]));
-						h = __builtin_elementwise_max(h, as_s(f));
-						H[r] = to_int(h);
-						const v2u ho = __builtin_elementwise_sub_sat(as_u(h), (v2u){ 2 * GAP_OPEN, 2 * GAP_OPEN });
-						E[r] = to_int(__builtin_elementwise_max(__builtin_elementwise_sub_sat(u_fromi(E[r]), (v2u){ 2 * GAP_EXT, 2 * GAP_EXT }), ho));
-						const v2u fnew = __builtin_elementwise_max(__builtin_elementwise_sub_sat(f, (v2u){ 2 * GAP_EXT, 2 * GAP_EXT }), ho);
-						if (r == RP - 1) {
-							// a half that owns only RP-1 rows passes F and its bottom H through unchanged
-							f = (fnew & actm) | (f & ~actm);
-							lmax = __builtin_elementwise_max(lmax, as_s(as_u(h) & actm));
-							if (RP > 1) hbot = (to_int(h) & (int)act) | (H[RP > 1 ? RP - 2 : 0] & ~(int)act);
-							else hbot = to_int(h);
-						} else {
-							f = fnew;
-							lmax = __builtin_elementwise_max(lmax, h);
-						}
-						hprev = hold;
-					}
-				}
+			for (int g = 0; g < NLOAD; g++) {
+				PA[g] = *reinterpret_cast<const v4i*>(pa + 16 * g);
+				if constexpr (!PAIR) PB[g] = *reinterpret_cast<const v4i*>(pb + 16 * g); else PB[g] = PA[g];
 			}
+			auto score_of = [&](int r) -> int {
+				const int g = r / ROWS_PER_LOAD, k = r % ROWS_PER_LOAD;
+				if constexpr (PAIR) return PA[g][k];
+				else return __builtin_amdgcn_perm(PB[g][k >> 1], PA[g][k >> 1], (k & 1) ? 0x07060302 : 0x05040100);
+			};
+			// Row r needs the OLD H[r-1] (diagonal) and writes the NEW H[r].  The add of row r+1 (old H[r] + its score) is
+			// issued before H[r] is overwritten, so the new value can go into the same register: no second copy of the H
+			// column and no register moves at the end of the step.
+			// (the sum is forced into the register of the score, which dies there: the compiler would otherwise add in place
+			//  over the old H, keep that register busy until the next row and have to park the new H somewhere else)
+			auto diag_plus_score = [](int hold, int sc) -> v2s { asm("v_pk_add_i16 %0, %1, %0 clamp" : "+v"(sc) : "v"(hold)); return s_from(sc); };
+			v2s t = diag_plus_score(hdiag0, score_of(0));
+#pragma unroll
+			for (int r = 0; r < RP; r++) {
+				v2s tnext = t;
+				if (r + 1 < RP) tnext = diag_plus_score(H[r], score_of(r + 1));
+				v2s h = __builtin_elementwise_max(t, s_from(E[r]));
+				// h = max(h, f), written into the register that held the OLD H[r] (tied dummy operand; its last real use was
+				// the sum for row r+1 above): the H column stays where it is from step to step
+				// (tnext is passed as an unused operand only to order this after the sum above, which still reads the old H[r])
+				{ int hn; asm("v_pk_max_i16 %0, %2, %3" : "=v"(hn) : "0"(H[r]), "v"(to_int(h)), "v"(to_int(f)), "v"(to_int(tnext))); h = s_from(hn); }
+				H[r] = to_int(h);
+				const v2u ho = __builtin_elementwise_sub_sat(as_u(h), (v2u){ 2 * GAP_OPEN, 2 * GAP_OPEN });
+				E[r] = to_int(__builtin_elementwise_max(__builtin_elementwise_sub_sat(u_fromi(E[r]), (v2u){ 2 * GAP_EXT, 2 * GAP_EXT }), ho));
+				const v2u fnew = __builtin_elementwise_max(__builtin_elementwise_sub_sat(f, (v2u){ 2 * GAP_EXT, 2 * GAP_EXT }), ho);
+				if (r == RP - 1) {
+					// a half that owns only RP-1 rows passes F and its bottom H through unchanged
+					f = (fnew & actm) | (f & ~actm);
+					lmx[r & 3] = __builtin_elementwise_max(lmx[r & 3], as_s(as_u(h) & actm));
+					if (RP > 1) hbot = (to_int(h) & (int)act) | (H[RP > 1 ? RP - 2 : 0] & ~(int)act);
+					else hbot = to_int(h);
+				} else {
+					f = fnew;
+					lmx[r & 3] = __builtin_elementwise_max(lmx[r & 3], h);
+				}
+				t = tnext;
+			}
+			const v2s lmax = __builtin_elementwise_max(__builtin_elementwise_max(lmx[0], lmx[1]), __builtin_elementwise_max(lmx[2], lmx[3]));
+			// pin the reduction here: if the compiler sinks it below the hazard branch, the 22 pre-branch H values stay alive
+			// next to the (possibly tainted) ones and the common path pays a register copy per row at the join
+			asm volatile("" :: "v"(to_int(lmax)));
 			fbot = to_int(f);
 			// ---- Q2 hazard.  The reference's lazy-F loop leaves early (signed compare, sswNew.cpp:369) only while a
 			// stripe's propagated boundary value Fp = F[b] - 4j is >= 132 and the H it has just corrected is < 144
@@ -272,6 +300,10 @@ __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves
 					const v2u one = (v2u){ 1, 1 };
 					constexpr uint32_t K1 = 0x00010001u, K263 = 263u * 0x10001u, K288 = 288u * 0x10001u, KE = (2u * GAP_EXT) * 0x10001u,
 						KO = (2u * GAP_OPEN) * 0x10001u;
+					// pass 1 only READS H and E and collects the taint decisions as bit r of (dh, de)[r / 16]; pass 2 ORs them
+					// in.  Every read of the old value thus precedes the in-place update, so H[r] / E[r] stay in the registers
+					// the common path uses and the join needs no copies.
+					uint32_t dh[2] = { 0u, 0u }, de[2] = { 0u, 0u };
 #pragma unroll
 					for (int r = 0; r < RP; r++) {
 						const v2u hr = u_fromi(H[r]);
@@ -286,10 +318,15 @@ __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves
 						// E of this row was just derived from the untainted H: taint it when it came from H (or ties with it)
 						const v2u ho = pk_subs_k(hr, KO);
 						const v2u efrom = pk_minu(pk_ksubs(K1, pk_subs(u_fromi(E[r]), ho)), ho);
-						H[r] |= to_int(dev);
-						E[r] |= to_int(pk_minu(efrom, dev));
+						dh[r >> 4] |= (uint32_t)to_int(dev) << (r & 15);
+						de[r >> 4] |= (uint32_t)to_int(pk_minu(efrom, dev)) << (r & 15);
 						arm = pk_maxu(arm, pk_minu(ge, lt));
 						fp = nfp;
+					}
+#pragma unroll
+					for (int r = 0; r < RP; r++) {
+						or_in_place(H[r], (int)((dh[r >> 4] >> (r & 15)) & K1));
+						or_in_place(E[r], (int)((de[r >> 4] >> (r & 15)) & K1));
 					}
 					if (RP > 1) hbot = (H[RP - 1] & (int)act) | (H[RP > 1 ? RP - 2 : 0] & ~(int)act);
 					else hbot = H[0];
@@ -306,7 +343,10 @@ __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves
 				if (last_tile) out[cdone] = (uint16_t)((uint32_t)cm >> 16);
 				else bnd[cdone] = make_uint2(((uint32_t)hbot >> 16) | ((uint32_t)fbot & 0xffff0000u), ((uint32_t)cm >> 16) | ((uint32_t)fpo & 0xffff0000u));
 			}
-		}
+		};
+		int step = 0;
+		for (; step + 1 < nsteps; step += 2) { do_step(step); do_step(step + 1); }
+		if (step < nsteps) do_step(step);
 		if (a.unit_hz && __builtin_amdgcn_ballot_w64(to_int(hzacc) != 0) != 0ull && lane == 0) atomicOr(a.unit_hz + unit, 1);
 	}
 }
