@@ -69,6 +69,14 @@ __device__ __forceinline__ v2u pk_maxu(v2u a, v2u b) { v2u r; asm("v_pk_max_u16 
 // pay a v_mov per row in every step)
 __device__ __forceinline__ void or_in_place(int& x, int bits) { asm volatile("v_or_b32 %0, %0, %1" : "+v"(x) : "v"(bits)); }
 
+// the same shift with zeros entering virtual lane 0 (bound_ctrl: an out-of-range source lane reads as 0): no register has to
+// be preloaded with the value to inject
+__device__ __forceinline__ int vshift0(int x)
+{
+	const int up = __builtin_amdgcn_mov_dpp(x, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+	return __builtin_amdgcn_alignbit(x, up, 16);
+}
+
 constexpr int SCAN_RS = 24;                 // storage rows per virtual lane in the LDS profile
 constexpr int SCAN_LANE_STRIDE = 112;       // bytes: 2 halves x 24 rows x 2 B + 16 B pad (bank-conflict-free b128)
 constexpr int SCAN_CODE_STRIDE = 64 * SCAN_LANE_STRIDE;   // 7168 B, a multiple of the 256-B bank row
@@ -177,7 +185,8 @@ __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves
 	const v2u startm = __builtin_bit_cast(v2u, startbits);
 	// the refined test needs F to die inside one stripe (F <= 234 decays by 4 per row)
 	const bool lvl2 = a.seg_len16 >= 96 && !a.coarse;
-	const uint8_t* pl = prof + (PAIR ? pair_lane_offset(lane) : lane * SCAN_LANE_STRIDE);
+	const int pl_off = PAIR ? pair_lane_offset(lane) : lane * SCAN_LANE_STRIDE;
+	const uint8_t* pl = prof + pl_off;
 
 	for (;;) {
 		int w = 0;
@@ -213,20 +222,21 @@ __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves
 				if (!first_tile) bchunk = c < n ? bnd[c] : make_uint2(0u, 0u);     // bottom row of the previous tile
 			}
 			const int newcode = __builtin_amdgcn_readlane(chunk, step & 63);
-			int in_h = 0, in_f = 0, in_cm = 0, in_fp = 0;
-			if (!first_tile) {
+			// hand-over from virtual lane v-1 (computed one step ago; lane 0 takes zeros or the previous tile's bottom row)
+			tc = vshift(tc, newcode << 16);
+			int recv_h, recv_f, recv_cm, recv_fp;
+			if (first_tile) {
+				recv_h = vshift0(hbot); recv_f = vshift0(fbot); recv_cm = vshift0(cm); recv_fp = vshift0(fpo);
+			} else {
 				const uint32_t bx = (uint32_t)__builtin_amdgcn_readlane((int)bchunk.x, step & 63);
 				const uint32_t by = (uint32_t)__builtin_amdgcn_readlane((int)bchunk.y, step & 63);
-				in_h = (int)(bx << 16); in_f = (int)(bx & 0xffff0000u); in_cm = (int)(by << 16); in_fp = (int)(by & 0xffff0000u);
+				recv_h = vshift(hbot, (int)(bx << 16)); recv_f = vshift(fbot, (int)(bx & 0xffff0000u));
+				recv_cm = vshift(cm, (int)(by << 16)); recv_fp = vshift(fpo, (int)(by & 0xffff0000u));
 			}
-			// hand-over from virtual lane v-1 (computed one step ago; lane 0 takes the previous tile's bottom row)
-			tc = vshift(tc, newcode << 16);
-			const int recv_h = vshift(hbot, in_h);
-			const int recv_f = vshift(fbot, in_f);
-			const int recv_cm = vshift(cm, in_cm);
-			const int recv_fp = vshift(fpo, in_fp);
 			const int t_lo = tc & 0xff, t_hi = (tc >> 16) & 0xff;
-			const uint8_t* pa = PAIR ? pl + (t_lo * 5 + t_hi) * PAIR_STRIDE : pl + t_lo * SCAN_CODE_STRIDE;
+			// PAIR: byte offset of the pair's rows = t_lo * 5 * PAIR_STRIDE + t_hi * PAIR_STRIDE + lane offset: one v_dot2_u32_u16
+			const uint8_t* pa = PAIR ? prof + __builtin_amdgcn_udot2(__builtin_bit_cast(v2u, tc), (v2u){ 5 * PAIR_STRIDE, PAIR_STRIDE }, (unsigned)pl_off, false)
+			                         : pl + t_lo * SCAN_CODE_STRIDE;
 			const uint8_t* pb = pl + t_hi * SCAN_CODE_STRIDE + 48;      // (!PAIR only)
 			const int hdiag0 = recv_h_last;           // H[i0-1][c-1]
 			recv_h_last = recv_h;
@@ -291,11 +301,19 @@ __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves
 			fpo = 0;
 			if (lvl2) {
 				// fpo halves: bits 0..14 = propagated value, bit 15 = "an early exit was possible at an earlier row"
-				const v2u fpraw = (__builtin_bit_cast(v2u, recv_f) & startm) | (__builtin_bit_cast(v2u, recv_fp) & ~startm);
-				const v2u fp_in = fpraw & (v2u){ 0x7fff, 0x7fff };
-				const v2u arm_in = (fpraw >> (v2u){ 15, 15 }) & ~startm;
-				const v2u hot = pk_subs_k(fp_in, 263u * 0x10001u) | pk_minu(arm_in, fp_in);
-				if (__builtin_amdgcn_ballot_w64(to_int(hot) != 0) != 0ull) {
+				// cheap superset first (3 VALU): a stripe-start lane receives F >= 132, or some lane receives a live chain;
+				// the exact condition is only evaluated behind it
+				const v2u cand = pk_subs_k(__builtin_bit_cast(v2u, recv_f) & startm, 263u * 0x10001u) | __builtin_bit_cast(v2u, recv_fp);
+				bool enter = false;
+				v2u fp_in = (v2u){ 0, 0 }, arm_in = (v2u){ 0, 0 };
+				if (__builtin_amdgcn_ballot_w64(to_int(cand) != 0) != 0ull) {
+					const v2u fpraw = (__builtin_bit_cast(v2u, recv_f) & startm) | (__builtin_bit_cast(v2u, recv_fp) & ~startm);
+					fp_in = fpraw & (v2u){ 0x7fff, 0x7fff };
+					arm_in = (fpraw >> (v2u){ 15, 15 }) & ~startm;
+					const v2u hot = pk_subs_k(fp_in, 263u * 0x10001u) | pk_minu(arm_in, fp_in);
+					enter = __builtin_amdgcn_ballot_w64(to_int(hot) != 0) != 0ull;
+				}
+				if (enter) {
 					v2u fp = fp_in, arm = arm_in;
 					const v2u one = (v2u){ 1, 1 };
 					constexpr uint32_t K1 = 0x00010001u, K263 = 263u * 0x10001u, K288 = 288u * 0x10001u, KE = (2u * GAP_EXT) * 0x10001u,
