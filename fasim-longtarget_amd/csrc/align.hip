@@ -48,6 +48,15 @@ __device__ __forceinline__ v2u apk_minu(v2u a, v2u b) { v2u r; asm("v_pk_min_u16
 __device__ __forceinline__ v2u apk_minu_k(v2u a, uint32_t k) { v2u r; asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "s"(k)); return r; }
 __device__ __forceinline__ v2u apk_maxu(v2u a, v2u b) { v2u r; asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
+// x |= bits with input and output tied to one register (see scan.hip)
+__device__ __forceinline__ void a_or_in_place(int& x, int bits) { asm volatile("v_or_b32 %0, %0, %1" : "+v"(x) : "v"(bits)); }
+// the pipeline shift with zeros entering virtual lane 0 (no register to preload)
+__device__ __forceinline__ int vshift2_zero(int x)
+{
+	const int up = __builtin_amdgcn_mov_dpp(x, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+	return __builtin_amdgcn_alignbit(x, up, 16);
+}
+
 __device__ __forceinline__ int vshift2(int x, int inject_hi)
 {
 	const int up = __builtin_amdgcn_update_dpp(inject_hi, x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
@@ -180,19 +189,22 @@ __global__ void __launch_bounds__(256) k_align_fwd(FwdArgs a)
 				if (!first_tile) bchunk = c < slen ? bnd[c] : make_uint4(0u, 0u, 0u, 0u);
 			}
 			int newcode = __builtin_amdgcn_readlane(chunk, step & 63);
-			int in_h = 0, in_f = 0, in_fp = 0, in_k = 0;
-			if (!first_tile) {
+			int recv_h, recv_f, recv_fp;
+			uint32_t kup;
+			if (first_tile) {
+				// zeros enter virtual lane 0 (bound_ctrl): nothing to preload
+				tc = vshift2(tc, newcode << 16);
+				recv_h = vshift2_zero(hbot); recv_f = vshift2_zero(fbot); recv_fp = vshift2_zero(fpo);
+				kup = (uint32_t)__builtin_amdgcn_mov_dpp((int)khi, 0x138, 0xf, 0xf, true);
+			} else {
 				const uint32_t bx = (uint32_t)__builtin_amdgcn_readlane((int)bchunk.x, step & 63);
 				const uint32_t by = (uint32_t)__builtin_amdgcn_readlane((int)bchunk.y, step & 63);
-				in_k = __builtin_amdgcn_readlane((int)bchunk.z, step & 63);
-				in_h = (int)(bx << 16); in_f = (int)(bx & 0xffff0000u); in_fp = (int)(by << 16);
+				const int in_k = __builtin_amdgcn_readlane((int)bchunk.z, step & 63);
 				newcode |= (int)((by >> 16) & TAG_HZ);              // hazard seen by the tiles above
+				tc = vshift2(tc, newcode << 16);
+				recv_h = vshift2(hbot, (int)(bx << 16)); recv_f = vshift2(fbot, (int)(bx & 0xffff0000u)); recv_fp = vshift2(fpo, (int)(by << 16));
+				kup = (uint32_t)__builtin_amdgcn_update_dpp(in_k, (int)khi, 0x138, 0xf, 0xf, false);
 			}
-			tc = vshift2(tc, newcode << 16);
-			const int recv_h = vshift2(hbot, in_h);
-			const int recv_f = vshift2(fbot, in_f);
-			const int recv_fp = vshift2(fpo, in_fp);
-			const uint32_t kup = (uint32_t)__builtin_amdgcn_update_dpp(in_k, (int)khi, 0x138, 0xf, 0xf, false);
 			const uint32_t kin_lo = kup, kin_hi = klo;       // from virtual lane v-1 (same column, one step ago)
 			const int t_lo = tc & 7, t_hi = (tc >> 16) & 7;
 			const uint8_t* pa = pl + t_lo * AL_CODE_STRIDE;
@@ -201,56 +213,77 @@ __global__ void __launch_bounds__(256) k_align_fwd(FwdArgs a)
 			const v2u isvoid = (v2u){ (unsigned short)(t_lo == CODE_VOID ? 0xFFFF : 0), (unsigned short)(t_hi == CODE_VOID ? 0xFFFF : 0) };
 			const v2u dec = isvoid | (v2u){ GAP_EXT * SC, GAP_EXT * SC };
 			const v2u gapo = isvoid | (v2u){ GAP_OPEN * SC, GAP_OPEN * SC };
-			int hprev = recv_h_last;
+			const int hdiag0 = recv_h_last;
 			recv_h_last = recv_h;
 			v2u f = u_from(recv_f);
-			v2s lkey = (v2s){ 0, 0 };
+			v2s lkx[4] = { (v2s){ 0, 0 }, (v2s){ 0, 0 }, (v2s){ 0, 0 }, (v2s){ 0, 0 } };      // independent max chains
+			constexpr int NLOAD = (RP + 7) / 8;
+			v4i PA[NLOAD], PB[NLOAD];
 #pragma unroll
-			for (int g = 0; g < (RP + 7) / 8; g++) {
-				const v4i A = *reinterpret_cast<const v4i*>(pa + 16 * g);
-				const v4i B = *reinterpret_cast<const v4i*>(pb + 16 * g);
-#pragma unroll
-				for (int k = 0; k < 8; k++) {
-					const int r = 8 * g + k;
-					if (r < RP) {
-						const int sc = __builtin_amdgcn_perm(B[k >> 1], A[k >> 1], (k & 1) ? 0x07060302 : 0x05040100);
-						const int hold = H[r];
-						v2s h = TAINT ? __builtin_elementwise_add_sat(s_fromi(hprev), s_fromi(sc)) : s_fromi(hprev) + s_fromi(sc);
-						h = __builtin_elementwise_max(h, s_fromi(E[r]));
-						h = __builtin_elementwise_max(h, a_s(f));
-						H[r] = a_i(h);
-						const v2u ho = __builtin_elementwise_sub_sat(a_u(h), gapo);
-						E[r] = a_i(__builtin_elementwise_max(__builtin_elementwise_sub_sat(u_from(E[r]), dec), ho));
-						const v2u fnew = __builtin_elementwise_max(__builtin_elementwise_sub_sat(f, dec), ho);
-						const v2s key = h | (v2s){ (short)(31 - r), (short)(31 - r) };
-						if (r == RP - 1) {
-							f = (fnew & actm) | (f & ~actm);
-							lkey = __builtin_elementwise_max(lkey, a_s(a_u(key) & actm));
-							if (RP > 1) hbot = (a_i(h) & (int)act) | (H[RP > 1 ? RP - 2 : 0] & ~(int)act);
-							else hbot = a_i(h);
-						} else {
-							f = fnew;
-							lkey = __builtin_elementwise_max(lkey, key);
-						}
-						hprev = hold;
-					}
-				}
+			for (int g = 0; g < NLOAD; g++) {
+				PA[g] = *reinterpret_cast<const v4i*>(pa + 16 * g);
+				PB[g] = *reinterpret_cast<const v4i*>(pb + 16 * g);
 			}
+			auto score_of = [&](int r) -> int {
+				const int g = r >> 3, k = r & 7;
+				return __builtin_amdgcn_perm(PB[g][k >> 1], PA[g][k >> 1], (k & 1) ? 0x07060302 : 0x05040100);
+			};
+			// (see scan.hip: the diagonal sum goes into the register of the score, the new H into the register of the old
+			//  H, so the H column needs no second copy and no moves at the end of the step)
+			auto diag_plus_score = [](int hold, int sc) -> v2s {
+				if (TAINT) asm("v_pk_add_i16 %0, %1, %0 clamp" : "+v"(sc) : "v"(hold));
+				else asm("v_pk_add_i16 %0, %1, %0" : "+v"(sc) : "v"(hold));
+				return s_fromi(sc);
+			};
+			v2s t = diag_plus_score(hdiag0, score_of(0));
+#pragma unroll
+			for (int r = 0; r < RP; r++) {
+				v2s tnext = t;
+				if (r + 1 < RP) tnext = diag_plus_score(H[r], score_of(r + 1));
+				v2s h = __builtin_elementwise_max(t, s_fromi(E[r]));
+				{ int hn; asm("v_pk_max_i16 %0, %2, %3" : "=v"(hn) : "0"(H[r]), "v"(a_i(h)), "v"(a_i(f)), "v"(a_i(tnext))); h = s_fromi(hn); }
+				H[r] = a_i(h);
+				const v2u ho = __builtin_elementwise_sub_sat(a_u(h), gapo);
+				E[r] = a_i(__builtin_elementwise_max(__builtin_elementwise_sub_sat(u_from(E[r]), dec), ho));
+				const v2u fnew = __builtin_elementwise_max(__builtin_elementwise_sub_sat(f, dec), ho);
+				const v2s key = h | (v2s){ (short)(31 - r), (short)(31 - r) };
+				if (r == RP - 1) {
+					f = (fnew & actm) | (f & ~actm);
+					lkx[r & 3] = __builtin_elementwise_max(lkx[r & 3], a_s(a_u(key) & actm));
+					if (RP > 1) hbot = (a_i(h) & (int)act) | (H[RP > 1 ? RP - 2 : 0] & ~(int)act);
+					else hbot = a_i(h);
+				} else {
+					f = fnew;
+					lkx[r & 3] = __builtin_elementwise_max(lkx[r & 3], key);
+				}
+				t = tnext;
+			}
+			const v2s lkey = __builtin_elementwise_max(__builtin_elementwise_max(lkx[0], lkx[1]), __builtin_elementwise_max(lkx[2], lkx[3]));
+			asm volatile("" :: "v"(a_i(lkey)));      // pin the reduction before the hazard branch (see scan.hip)
 			fbot = a_i(f);
 			// Q2 (8-bit pass only).  Short queries: any F[b] >= 132 entering a stripe flags the column (TAG_HZ).  Otherwise the
 			// row analysis of scan.hip marks the cells the reference's early lazy-F exit would have left smaller (taint bit).
 			fpo = 0;
 			if (TAINT) {
 				if (lvl2) {
-					const v2u fpraw = ((u_from(recv_f) & startm) | (u_from(recv_fp) & ~startm)) & ~isvoid;
-					const v2u fp_in = fpraw & (v2u){ 0x7fff, 0x7fff };
-					const v2u arm_in = (fpraw >> (v2u){ 15, 15 }) & ~startm;
 					constexpr uint32_t K1 = 0x00010001u, KGE = (uint32_t)(132 * SC - 1) * 0x10001u, KLT = (uint32_t)(144 * SC) * 0x10001u,
 						KE = (uint32_t)(GAP_EXT * SC) * 0x10001u, KO = (uint32_t)(GAP_OPEN * SC) * 0x10001u;
-					const v2u hot = apk_subs_k(fp_in, KGE) | apk_minu(arm_in, fp_in);
-					if (__builtin_amdgcn_ballot_w64(a_i(hot) != 0) != 0ull) {
+					// cheap superset first: a stripe-start lane receives F >= 132, or some lane receives a live chain
+					const v2u cand = apk_subs_k(u_from(recv_f) & startm, KGE) | u_from(recv_fp);
+					bool enter = false;
+					v2u fp_in = (v2u){ 0, 0 }, arm_in = (v2u){ 0, 0 };
+					if (__builtin_amdgcn_ballot_w64(a_i(cand) != 0) != 0ull) {
+						const v2u fpraw = ((u_from(recv_f) & startm) | (u_from(recv_fp) & ~startm)) & ~isvoid;
+						fp_in = fpraw & (v2u){ 0x7fff, 0x7fff };
+						arm_in = (fpraw >> (v2u){ 15, 15 }) & ~startm;
+						const v2u hot = apk_subs_k(fp_in, KGE) | apk_minu(arm_in, fp_in);
+						enter = __builtin_amdgcn_ballot_w64(a_i(hot) != 0) != 0ull;
+					}
+					if (enter) {
 						v2u fp = fp_in, arm = arm_in;
 						const v2u one = (v2u){ 1, 1 };
+						// pass 1 reads H / E and collects the decisions as bit r of (dh, de)[r / 16]; pass 2 ORs the taint bit in
+						uint32_t dh[2] = { 0u, 0u }, de[2] = { 0u, 0u };
 #pragma unroll
 						for (int r = 0; r < RP; r++) {
 							const v2u hr = u_from(H[r]);
@@ -262,10 +295,15 @@ __global__ void __launch_bounds__(256) k_align_fwd(FwdArgs a)
 							const v2u dev = apk_minu(apk_minu(eq, fp), arm);                            // 0 / 1
 							const v2u ho = apk_subs_k(hr, KO);
 							const v2u efrom = apk_minu(apk_ksubs(K1, apk_subs(u_from(E[r]), ho)), ho);
-							H[r] |= a_i(dev << (v2u){ 5, 5 });
-							E[r] |= a_i(apk_minu(efrom, dev) << (v2u){ 5, 5 });
+							dh[r >> 4] |= (uint32_t)a_i(dev) << (r & 15);
+							de[r >> 4] |= (uint32_t)a_i(apk_minu(efrom, dev)) << (r & 15);
 							arm = apk_maxu(arm, apk_minu(ge, lt));
 							fp = nfp;
+						}
+#pragma unroll
+						for (int r = 0; r < RP; r++) {
+							a_or_in_place(H[r], (int)(((dh[r >> 4] >> (r & 15)) & K1) << 5));
+							a_or_in_place(E[r], (int)(((de[r >> 4] >> (r & 15)) & K1) << 5));
 						}
 						if (RP > 1) hbot = (H[RP - 1] & (int)act) | (H[RP > 1 ? RP - 2 : 0] & ~(int)act);
 						else hbot = H[0];
@@ -284,32 +322,36 @@ __global__ void __launch_bounds__(256) k_align_fwd(FwdArgs a)
 			khi = kin_hi > loc_hi ? kin_hi : loc_hi;
 
 			// ---- pipe end: virtual lane 127 has just finished one column of the stream ---------------------
-			if (lane == 63 && !last_tile) {
+			if (!last_tile) {
 				// hand the bottom row of this tile to the next one (in place: this stream position was read 127 steps ago)
 				const int pos = step - 127;
-				if (pos >= 0 && pos < slen)
+				if (lane == 63 && pos >= 0 && pos < slen)
 					bnd[pos] = make_uint4(((uint32_t)hbot >> 16) | ((uint32_t)fbot & 0xffff0000u),
 						((uint32_t)fpo >> 16) | ((uint32_t)tc & 0xffff0000u), khi, 0u);
-			}
-			if (lane == 63 && last_tile) {
-				const int tag = (tc >> 16) & 0xff;
+			} else {
+				// everything below is wave-uniform: the two values of lane 63 are read into scalar registers and the
+				// bookkeeping runs on the scalar unit (it used to cost ~35 vector instructions per step for one active lane)
+				const int tag = (__builtin_amdgcn_readlane(tc, 63) >> 16) & 0xff;
+				const uint32_t k63 = (uint32_t)__builtin_amdgcn_readlane((int)khi, 63);
 				if ((tag & 7) != CODE_VOID) {
 					// TAINT: the key's value field is 2 * maximum + taint of the winning cell
-					const int cfield = (int)(khi >> 16);
+					const int cfield = (int)(k63 >> 16);
 					const int colmax = TAINT ? (cfield >> 1) : cfield;
 					// 8-bit pass: the reference stops at the first column whose maximum reaches 251 (overflow -> 16-bit pass), so
 					// nothing after that column matters (in particular not the saturated, hence "tainted", values further on)
 					if (!(TAINT && over)) {
 						if (tag & TAG_HZ) hzflag = 1;
-						if (colmax > runmax) { runmax = colmax; end_ref = cidx; end_read = 0xFFFF - (int)(khi & 0xFFFFu); wtaint = TAINT ? (cfield & 1) : 0; }
+						if (colmax > runmax) { runmax = colmax; end_ref = cidx; end_read = 0xFFFF - (int)(k63 & 0xFFFFu); wtaint = TAINT ? (cfield & 1) : 0; }
 						if (runmax >= 255 - BIAS) over = 1;
 					}
 					cidx++;
 					if (tag & TAG_LAST) {
-						FwdOut o;
-						o.score = runmax; o.ref_end = end_ref; o.read_end = end_read < a.m - 1 ? end_read : a.m - 1;
-						o.flags = hzflag | wtaint; o.ref_begin = 0; o.read_begin = 0;
-						a.out[pidx] = o;
+						if (lane == 0) {
+							FwdOut o;
+							o.score = runmax; o.ref_end = end_ref; o.read_end = end_read < a.m - 1 ? end_read : a.m - 1;
+							o.flags = hzflag | wtaint; o.ref_begin = 0; o.read_begin = 0;
+							a.out[pidx] = o;
+						}
 						pidx++; cidx = 0; runmax = 0; end_ref = -1; end_read = 0; hzflag = 0; over = 0; wtaint = 0;
 					}
 				}
