@@ -68,7 +68,8 @@ constexpr int AL_LANE_STRIDE = 112;
 constexpr int AL_CODE_STRIDE = 64 * AL_LANE_STRIDE;
 constexpr int AL_SCALE = 32;                 // DP values are multiples of 32
 constexpr int AL_NEG = -32768;               // void / dead score: H <= 31360 so H + AL_NEG < 0 always
-constexpr int CODE_VOID = 5;
+constexpr int CODE_VOID = 4;                 // stream codes: A0 C1 G2 T3, 4 = void column (between windows), 5 = N
+constexpr int CODE_SN = 5;                   // (the unit codes of kernels.h use 4 for N: k_build_stream re-codes)
 constexpr int TAG_LAST = 8;                  // bit 3 of a stream byte: last column of a window
 constexpr int TAG_HZ = 16;                   // bit 4 (in flight only): hazard seen in this column
 
@@ -83,7 +84,7 @@ __global__ void k_build_stream(const uint8_t* __restrict__ tcodes, const FwdProb
 	for (int c = threadIdx.x; c < pb.len + 2; c += blockDim.x) {
 		uint8_t v;
 		if (c < 2) v = CODE_VOID;
-		else { v = tcodes[pb.tbase + (c - 2)]; if (c - 2 == pb.len - 1) v |= TAG_LAST; }
+		else { v = tcodes[pb.tbase + (c - 2)]; if (v >= 4) v = CODE_SN; if (c - 2 == pb.len - 1) v |= TAG_LAST; }
 		s[c] = v;
 	}
 }
@@ -116,36 +117,61 @@ __device__ __forceinline__ void lane_rows_a(int v, int seg_len, int vs, int* row
 	*row0 = s * seg_len + j * q + (j < rem ? j : rem);
 }
 
-template <int RP, bool TAINT>
-__global__ void __launch_bounds__(256) k_align_fwd(FwdArgs a)
+// score of stream code t (0..3 bases, 4 void, 5 N) against the r-th row of global virtual lane v, scaled by sc
+__device__ __forceinline__ int fwd_cell_score(const FwdArgs& a, int t, int v, int r, int sc)
+{
+	int row0v, rows_v;
+	lane_rows_a(v, a.seg_len16, a.vs, &row0v, &rows_v);
+	if (t == CODE_VOID || r >= rows_v) return AL_NEG;
+	const int row = row0v + r;
+	if (row >= a.m) return 0;                 // zero-score pad rows (Q3)
+	const int q = a.qcodes[row];
+	return ((q == t && t < 4) ? 5 : -4) * sc;
+}
+
+// pair profile of the PAIR variant (see scan.hip): pairs over {A, C, G, T, void}; an N column is rare and patched in
+constexpr int FP_LANE_STRIDE = 96, FP_GROUP_STRIDE = 8 * FP_LANE_STRIDE + 16, FP_STRIDE = 6400, FP_LDS = 25 * FP_STRIDE;
+__device__ __forceinline__ int fp_lane_offset(int lane) { return (lane >> 3) * FP_GROUP_STRIDE + (lane & 7) * FP_LANE_STRIDE; }
+
+// PAIR = false: 256-thread workgroups, per-code int16 profile (43 KB) + one v_perm_b32 per row;
+// PAIR = true : 1024-thread workgroups, profile per pair of codes (156 KB), no perm
+template <int RP, bool TAINT, bool PAIR>
+__global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves_per_eu(PAIR ? 4 : 3, 4))) k_align_fwd(FwdArgs a)
 {
 	constexpr int SC = TAINT ? 2 * AL_SCALE : AL_SCALE;      // value scale; TAINT: bit 5 = taint, bits 0..4 = row tag
-	__shared__ __align__(16) uint8_t prof[6 * AL_CODE_STRIDE];
+	extern __shared__ __align__(16) uint8_t prof[];
 	const int lane = threadIdx.x & 63;
 
-	for (int idx = threadIdx.x; idx < 6 * 128 * AL_RS; idx += blockDim.x) {
-		const int r = idx % AL_RS;
-		const int v = (idx / AL_RS) % 128;
-		const int t = idx / (AL_RS * 128);
-		int row0v, rows_v;
-		lane_rows_a(128 * a.tile + v, a.seg_len16, a.vs, &row0v, &rows_v);
-		const int row = row0v + r;
-		int sc = AL_NEG;
-		if (t < 5 && r < rows_v) {
-			if (row < a.m) { const int q = a.qcodes[row]; sc = ((q == t && t < 4) ? 5 : -4) * SC; }
-			else sc = 0;
+	if constexpr (PAIR) {
+		for (int idx = threadIdx.x; idx < 25 * 64 * 24; idx += blockDim.x) {
+			const int r = idx % 24;
+			const int l = (idx / 24) % 64;
+			const int pr = idx / (24 * 64);
+			const int lo = fwd_cell_score(a, pr / 5, 128 * a.tile + 2 * l, r, SC);
+			const int hi = fwd_cell_score(a, pr % 5, 128 * a.tile + 2 * l + 1, r, SC);
+			*reinterpret_cast<uint32_t*>(prof + pr * FP_STRIDE + fp_lane_offset(l) + r * 4) = ((uint32_t)(uint16_t)(int16_t)lo) | ((uint32_t)(uint16_t)(int16_t)hi << 16);
 		}
-		*reinterpret_cast<int16_t*>(prof + t * AL_CODE_STRIDE + (v >> 1) * AL_LANE_STRIDE + (v & 1) * 48 + r * 2) = (int16_t)sc;
+	} else {
+		for (int idx = threadIdx.x; idx < 6 * 128 * AL_RS; idx += blockDim.x) {
+			const int r = idx % AL_RS;
+			const int v = (idx / AL_RS) % 128;
+			const int t = idx / (AL_RS * 128);
+			const int sc = fwd_cell_score(a, t, 128 * a.tile + v, r, SC);
+			*reinterpret_cast<int16_t*>(prof + t * AL_CODE_STRIDE + (v >> 1) * AL_LANE_STRIDE + (v & 1) * 48 + r * 2) = (int16_t)sc;
+		}
 	}
 	__syncthreads();
 
 	// stripe-aligned layout (see scan.hip): virtual lane 8k starts the reference's stripe k
 	uint32_t fthr = 0xFFFFFFFFu, act = 0, startbits = 0;
 	int row0[2];
+	uint32_t realc = 0, rowsc = 0;               // per half: rows with a real query letter / rows owned (N columns, PAIR)
 	for (int h = 0; h < 2; h++) {
 		const int v = 128 * a.tile + 2 * lane + h;
 		int rows_v;
 		lane_rows_a(v, a.seg_len16, a.vs, &row0[h], &rows_v);
+		const int real = a.m - row0[h] < 0 ? 0 : (a.m - row0[h] > rows_v ? rows_v : a.m - row0[h]);
+		realc |= (uint32_t)real << (16 * h); rowsc |= (uint32_t)rows_v << (16 * h);
 		if (v % a.vs == 0 && v > 0) { fthr = (fthr & ~(0xFFFFu << (16 * h))) | ((131u * SC + (SC - 1)) << (16 * h)); startbits |= 0xFFFFu << (16 * h); }
 		if (rows_v == RP) act |= 0xFFFFu << (16 * h);
 	}
@@ -153,7 +179,8 @@ __global__ void __launch_bounds__(256) k_align_fwd(FwdArgs a)
 	const v2u actm = u_from((int)act);
 	const v2u startm = u_from((int)startbits);
 	const bool lvl2 = a.seg_len16 >= 96;      // (the 16-bit pass, !TAINT, needs no Q2 test at all: its compare is unaffected)
-	const uint8_t* pl = prof + lane * AL_LANE_STRIDE;
+	const int pl_off = PAIR ? fp_lane_offset(lane) : lane * AL_LANE_STRIDE;
+	const uint8_t* pl = prof + pl_off;
 	// (31 - r) tags for the row keys, and the base of the global-row key of my two virtual lanes
 	const int kbase_lo = 0xFFFF - row0[0] - 31, kbase_hi = 0xFFFF - row0[1] - 31;
 
@@ -206,27 +233,50 @@ __global__ void __launch_bounds__(256) k_align_fwd(FwdArgs a)
 				kup = (uint32_t)__builtin_amdgcn_update_dpp(in_k, (int)khi, 0x138, 0xf, 0xf, false);
 			}
 			const uint32_t kin_lo = kup, kin_hi = klo;       // from virtual lane v-1 (same column, one step ago)
-			const int t_lo = tc & 7, t_hi = (tc >> 16) & 7;
-			const uint8_t* pa = pl + t_lo * AL_CODE_STRIDE;
-			const uint8_t* pb = pl + t_hi * AL_CODE_STRIDE + 48;
-			// void columns clear E and F: the saturating subtractions use 0xFFFF instead of 4*32 / 16*32
-			const v2u isvoid = (v2u){ (unsigned short)(t_lo == CODE_VOID ? 0xFFFF : 0), (unsigned short)(t_hi == CODE_VOID ? 0xFFFF : 0) };
+			const v2u tt = u_from(tc) & (v2u){ 7, 7 };                       // stream codes of my two halves
+			// void columns clear E and F: the saturating subtractions use 0xFFFF instead of 4*SC / 16*SC
+			const v2u isvoid = (v2u){ 0, 0 } - __builtin_elementwise_sub_sat((v2u){ 1, 1 }, tt ^ (v2u){ CODE_VOID, CODE_VOID });
 			const v2u dec = isvoid | (v2u){ GAP_EXT * SC, GAP_EXT * SC };
 			const v2u gapo = isvoid | (v2u){ GAP_OPEN * SC, GAP_OPEN * SC };
 			const int hdiag0 = recv_h_last;
 			recv_h_last = recv_h;
 			v2u f = u_from(recv_f);
 			v2s lkx[4] = { (v2s){ 0, 0 }, (v2s){ 0, 0 }, (v2s){ 0, 0 }, (v2s){ 0, 0 } };      // independent max chains
-			constexpr int NLOAD = (RP + 7) / 8;
+			constexpr int ROWS_PER_LOAD = PAIR ? 4 : 8;
+			constexpr int NLOAD = (RP + ROWS_PER_LOAD - 1) / ROWS_PER_LOAD;
 			v4i PA[NLOAD], PB[NLOAD];
+			if constexpr (PAIR) {
+				// pair index = min(code, 4) of the two halves (an N half borrows the void rows and is patched below)
+				const v2u pc = __builtin_elementwise_min(tt, (v2u){ 4, 4 });
+				const uint8_t* pp = prof + __builtin_amdgcn_udot2(pc, (v2u){ 5 * FP_STRIDE, FP_STRIDE }, (unsigned)pl_off, false);
 #pragma unroll
-			for (int g = 0; g < NLOAD; g++) {
-				PA[g] = *reinterpret_cast<const v4i*>(pa + 16 * g);
-				PB[g] = *reinterpret_cast<const v4i*>(pb + 16 * g);
+				for (int g = 0; g < NLOAD; g++) { PA[g] = *reinterpret_cast<const v4i*>(pp + 16 * g); PB[g] = PA[g]; }
+				const v2u isn = __builtin_elementwise_sub_sat(tt, (v2u){ 4, 4 });    // 1 where the half sits on an N column
+				if (__builtin_amdgcn_ballot_w64(a_i(isn) != 0) != 0ull) {
+					// N scores -4 against every real row, 0 against the pad rows, and rows beyond the half's share stay dead
+					const v2u nmask = (v2u){ 0, 0 } - isn;
+#pragma unroll
+					for (int r = 0; r < RP; r++) {
+						const v2u isreal = __builtin_elementwise_min(__builtin_elementwise_sub_sat(u_from((int)realc), (v2u){ (unsigned short)r, (unsigned short)r }), (v2u){ 1, 1 });
+						const v2u islive = __builtin_elementwise_min(__builtin_elementwise_sub_sat(u_from((int)rowsc), (v2u){ (unsigned short)r, (unsigned short)r }), (v2u){ 1, 1 });
+						const v2u nsc = (isreal * (v2u){ (unsigned short)(-4 * SC), (unsigned short)(-4 * SC) }) | ((islive - (v2u){ 1, 1 }) & (v2u){ 0x8000, 0x8000 });
+						const int g = r >> 2, k = r & 3;
+						PA[g][k] = (int)(((uint32_t)PA[g][k] & ~(uint32_t)a_i(nmask)) | ((uint32_t)a_i(nsc) & (uint32_t)a_i(nmask)));
+					}
+				}
+			} else {
+				const int t_lo = tc & 7, t_hi = (tc >> 16) & 7;
+				const uint8_t* pa = pl + t_lo * AL_CODE_STRIDE;
+				const uint8_t* pb = pl + t_hi * AL_CODE_STRIDE + 48;
+#pragma unroll
+				for (int g = 0; g < NLOAD; g++) {
+					PA[g] = *reinterpret_cast<const v4i*>(pa + 16 * g);
+					PB[g] = *reinterpret_cast<const v4i*>(pb + 16 * g);
+				}
 			}
 			auto score_of = [&](int r) -> int {
-				const int g = r >> 3, k = r & 7;
-				return __builtin_amdgcn_perm(PB[g][k >> 1], PA[g][k >> 1], (k & 1) ? 0x07060302 : 0x05040100);
+				if constexpr (PAIR) return PA[r >> 2][r & 3];
+				else { const int g = r >> 3, k = r & 7; return __builtin_amdgcn_perm(PB[g][k >> 1], PA[g][k >> 1], (k & 1) ? 0x07060302 : 0x05040100); }
 			};
 			// (see scan.hip: the diagonal sum goes into the register of the score, the new H into the register of the old
 			//  H, so the H column needs no second copy and no moves at the end of the step)
@@ -360,16 +410,22 @@ __global__ void __launch_bounds__(256) k_align_fwd(FwdArgs a)
 	}
 }
 
-template <int RP, bool TAINT>
+template <int RP, bool TAINT, bool PAIR>
 static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st)
 {
 	hipError_t err = hipMemsetAsync(a.counter, 0, sizeof(uint32_t), st);
 	if (err != hipSuccess) return err;
-	// 4 waves share one 43 KB profile: 3 workgroups per CU (512-thread workgroups for 4 waves per SIMD measured slower)
 	// (the host sizes the tasks so that there are about 3072 of them: one task per wave, workgroups are short-lived)
-	long blocks = ((long)a.ntask + 3) / 4;
-	if (blocks > 256 * 3) blocks = 256 * 3;
-	hipLaunchKernelGGL((k_align_fwd<RP, TAINT>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+	constexpr int WPB = PAIR ? 16 : 4;
+	long blocks = ((long)a.ntask + WPB - 1) / WPB;
+	const long cap = PAIR ? 256 : 256 * 3;
+	if (blocks > cap) blocks = cap;
+	const size_t lds = PAIR ? (size_t)FP_LDS : (size_t)6 * AL_CODE_STRIDE;
+	if (PAIR) {
+		static bool attr_set = false;
+		if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_align_fwd<RP, TAINT, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+	}
+	hipLaunchKernelGGL((k_align_fwd<RP, TAINT, PAIR>), dim3((unsigned)blocks), dim3(PAIR ? 1024 : 256), lds, st, a);
 	return hipGetLastError();
 }
 
@@ -383,11 +439,13 @@ hipError_t launch_align_fwd(const FwdLaunch& L, hipStream_t st)
 	a.vs = systolic_vs(L.m); a.ntiles = a.vs / 8; a.boundary = L.boundary;
 	if (a.ntiles > 1 && !a.boundary) return hipErrorInvalidValue;
 	const int rp = (a.seg_len16 + a.vs - 1) / a.vs;
+	static const bool pair = [] { const char* e = getenv("FASIM_FWD_PAIR"); return e ? atoi(e) != 0 : false; }();   // off: see DESIGN.md
 	for (int t = 0; t < a.ntiles; t++) {
 		a.tile = t;
 		hipError_t err = hipErrorInvalidValue;
 		switch (rp) {
-#define FASIM_FWD_CASE(N) case N: err = L.word ? launch_fwd_t<N, false>(a, st) : launch_fwd_t<N, true>(a, st); break;
+#define FASIM_FWD_CASE(N) case N: err = pair ? (L.word ? launch_fwd_t<N, false, true>(a, st) : launch_fwd_t<N, true, true>(a, st)) \
+                                             : (L.word ? launch_fwd_t<N, false, false>(a, st) : launch_fwd_t<N, true, false>(a, st)); break;
 		FASIM_FWD_CASE(1) FASIM_FWD_CASE(2) FASIM_FWD_CASE(3) FASIM_FWD_CASE(4) FASIM_FWD_CASE(5) FASIM_FWD_CASE(6)
 		FASIM_FWD_CASE(7) FASIM_FWD_CASE(8) FASIM_FWD_CASE(9) FASIM_FWD_CASE(10) FASIM_FWD_CASE(11) FASIM_FWD_CASE(12)
 		FASIM_FWD_CASE(13) FASIM_FWD_CASE(14) FASIM_FWD_CASE(15) FASIM_FWD_CASE(16) FASIM_FWD_CASE(17) FASIM_FWD_CASE(18)

@@ -412,7 +412,7 @@ hipError_t launch_scan(const ScanLaunch& L, hipStream_t st)
 	// RP must be exactly ceil(segLen/vs): every virtual lane then owns RP or RP-1 rows.  One launch per tile of 128
 	// virtual lanes (long queries): tile t reads the bottom row tile t-1 left in `boundary` and overwrites it in place.
 	const int rp = (a.seg_len16 + a.vs - 1) / a.vs;
-	static const bool pair = [] { const char* e = getenv("FASIM_SCAN_PAIR"); return e ? atoi(e) != 0 : true; }();
+	static const bool pair = [] { const char* e = getenv("FASIM_SCAN_PAIR"); return e ? atoi(e) != 0 : false; }();   // off: see DESIGN.md
 	for (int t = 0; t < a.ntiles; t++) {
 		a.tile = t;
 		hipError_t err = hipErrorInvalidValue;
