@@ -13,6 +13,7 @@
 // diagonal H and of the lazy-F value uses 16-wide wave shuffles; target codes are read 16 columns at a
 // time (one coalesced byte per lane) and broadcast by shuffle.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <type_traits>
 #include "kernels.h"
@@ -350,7 +351,10 @@ static hipError_t launch_striped_t(const StripedLaunch& L, hipStream_t st)
 	// up to four 16-lane groups (problems) per one-wave workgroup; long queries get fewer groups so that one group's
 	// H/E/query stripes still fit the 160 KB of LDS
 	int groups = (int)(((size_t)160 * 1024 - (SHARED_Q ? qbytes : 0)) / gbytes);
-	if (groups > 4) groups = 4;
+	// FASIM_STRIPED_GROUPS caps the problems per workgroup (default 4): two keep a workgroup's LDS below the ~20 KB that
+	// four k_scan workgroups leave free on a CU, so these latency-bound kernels can start while a scan is running
+	static const int max_groups = [] { const char* e = getenv("FASIM_STRIPED_GROUPS"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+	if (groups > max_groups) groups = max_groups;
 	if (groups < 1) return hipErrorInvalidValue;           // query too long for the LDS-resident kernel
 	const size_t shmem = (size_t)groups * gbytes + (SHARED_Q ? qbytes : 0);
 	auto kern = k_striped<MODE, WORD, QUIRK>;
