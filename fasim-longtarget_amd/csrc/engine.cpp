@@ -727,11 +727,17 @@ int run_finish(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb
 			if (big.empty()) break;
 			if (g_prof.on) g_prof.add(17 + pass, pass ? "finish: alignments sent to the 1 MB pass (count)" : "finish: alignments sent to the 16 KB pass (count)", 1e-6 * big.size());
 			rc = upload(E, E->unit_ids, big.data(), sizeof(int32_t) * big.size()); if (rc) return rc;
-			HIPOK(E->scratch2.ensure(big.size() * (size_t)caps[pass]));
-			{ TimedScope ts(E, 6);
-			he = launch_finish_big(E->tcodes.as<uint8_t>(), E->q2.as<uint8_t>(), E->fprobs.as<FwdProb>(), E->fout.as<FwdOut>(),
-				E->unit_ids.as<int32_t>(), (int)big.size(), E->scratch2.as<uint8_t>(), caps[pass], E->aout.as<AlignOutDev>(),
-				E->cigpool.as<uint32_t>(), (uint32_t)pool_cap, E->cigcount.as<uint32_t>(), E->st); }
+			// at most 2 GiB of scratch per launch (the 1 MB pass of a pathological batch is cut into slices)
+			const size_t per_launch = std::max<size_t>(64, ((size_t)2 << 30) / (size_t)caps[pass]);
+			HIPOK(E->scratch2.ensure(std::min(big.size(), per_launch) * (size_t)caps[pass]));
+			for (size_t b0 = 0; b0 < big.size(); b0 += per_launch) {
+				const size_t cnt = std::min(per_launch, big.size() - b0);
+				{ TimedScope ts(E, 6);
+				he = launch_finish_big(E->tcodes.as<uint8_t>(), E->q2.as<uint8_t>(), E->fprobs.as<FwdProb>(), E->fout.as<FwdOut>(),
+					E->unit_ids.as<int32_t>() + b0, (int)cnt, E->scratch2.as<uint8_t>(), caps[pass], E->aout.as<AlignOutDev>(),
+					E->cigpool.as<uint32_t>(), (uint32_t)pool_cap, E->cigcount.as<uint32_t>(), E->st); }
+				if (he != hipSuccess) break;
+			}
 			if (he != hipSuccess) return fail(E, FASIM_E_HIP, "finish (global scratch) launch failed: %s", hipGetErrorString(he));
 			HIPOK(hipMemcpyAsync(ao.data(), E->aout.p, sizeof(AlignOutDev) * n, hipMemcpyDeviceToHost, E->st));
 			HIPOK(hipMemcpyAsync(&pool_used, E->cigcount.p, sizeof pool_used, hipMemcpyDeviceToHost, E->st));
