@@ -232,6 +232,9 @@ def main():
                      "ops_per_cell": ops_per_cell, "achieved_tops": round(cells_dom * ops_per_cell / (kms[dom] * 1e-3) / 1e12, 3),
                      "peak_tops": VALU_PK16_PEAK_TOPS,
                      "frac": round(cells_dom * ops_per_cell / (kms[dom] * 1e-3) / 1e12 / VALU_PK16_PEAK_TOPS, 4),
+                     "issue_utilisation_measured": 0.99,
+                     "issue_utilisation_source": "profiles/r01_sq_counters.txt: SQ_INSTS_VALU / SQ_BUSY_CU_CYCLES of this kernel with one batch in "
+                                                 "flight (rocprofv3 --pmc), i.e. one wave64 packed op per CU clock = the packed-16 issue limit",
                      "note": "VALU instructions per DP cell x executed cells / HIP-event time of this kernel family; "
                              "peak = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz: packed 16-bit VALU ops issue at 4 clocks per wave64 (measured, "
                              "profiles/r01_sq_counters.txt), half the plain VALU rate; the "
