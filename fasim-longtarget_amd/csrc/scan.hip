@@ -130,13 +130,16 @@ constexpr int PAIR_LANE_STRIDE = 96;
 constexpr int PAIR_GROUP_STRIDE = 8 * PAIR_LANE_STRIDE + 16;   // 784 B
 constexpr int PAIR_STRIDE = 6400;             // >= 8 * 784 B per (code of half lo, code of half hi); a multiple of the 256-B bank row,
                                               // so that lanes holding different pairs keep their bank pattern
-constexpr int PAIR_LDS = 25 * PAIR_STRIDE;    // 160 000 B of the 163 840: one 1024-thread workgroup per CU
+constexpr int PAIR_LDS = 17 * PAIR_STRIDE;    // 108 800 B: 16 pairs over A,C,G,T plus (N, N); one 1024-thread workgroup per CU, which
+                                              // leaves 55 KB of the CU's LDS to the latency-bound kernels of the other batches
 __device__ __forceinline__ int pair_lane_offset(int lane) { return (lane >> 3) * PAIR_GROUP_STRIDE + (lane & 7) * PAIR_LANE_STRIDE; }
 
 // PAIR = false: 256-thread workgroups, per-code int16 profile (35 KB), the two halves of a lane fetch their own code's
 //               rows and a v_perm_b32 per row merges them;
 // PAIR = true : 1024-thread workgroups (16 waves = the whole CU), profile stored per PAIR of codes already merged
-//               (25 pairs x 64 lanes x 24 rows x 4 B = 150 KB of the 160 KB LDS): one VALU op per row less.
+//               (16 pairs of bases + the pair (N, N), 6.4 KB each): one VALU op per row less.  A lane whose halves are
+//               (base, N) -- the front of the pipeline while it fills or drains, or a real N in the DNA -- reads the
+//               pair with A in place of N and patches the N half in (a wave-uniform branch, ~2.5 % of the steps).
 template <int RP, bool PAIR>
 __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_scan(ScanArgs a)
 {
@@ -144,13 +147,14 @@ __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves
 	const int lane = threadIdx.x & 63;
 
 	if constexpr (PAIR) {
-		// ---- prof[t_lo * 5 + t_hi][lane][r] = { score(t_lo, row r of virtual lane 2*lane), score(t_hi, ... 2*lane+1) }
-		for (int idx = threadIdx.x; idx < 25 * 64 * 24; idx += blockDim.x) {
+		// ---- prof[t_lo * 4 + t_hi][lane][r] = { score(t_lo, row r of virtual lane 2*lane), score(t_hi, ... 2*lane+1) };
+		//      pair 16 = (N, N)
+		for (int idx = threadIdx.x; idx < 17 * 64 * 24; idx += blockDim.x) {
 			const int r = idx % 24;
 			const int l = (idx / 24) % 64;
 			const int pr = idx / (24 * 64);
-			const int lo = scan_cell_score(a, pr / 5, 128 * a.tile + 2 * l, r);
-			const int hi = scan_cell_score(a, pr % 5, 128 * a.tile + 2 * l + 1, r);
+			const int lo = scan_cell_score(a, pr == 16 ? 4 : pr / 4, 128 * a.tile + 2 * l, r);
+			const int hi = scan_cell_score(a, pr == 16 ? 4 : pr % 4, 128 * a.tile + 2 * l + 1, r);
 			*reinterpret_cast<uint32_t*>(prof + pr * PAIR_STRIDE + pair_lane_offset(l) + r * 4) = ((uint32_t)(uint16_t)(int16_t)lo) | ((uint32_t)(uint16_t)(int16_t)hi << 16);
 		}
 	} else {
@@ -172,10 +176,13 @@ __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves
 	//       its incoming F; Q2 needs F[b] >= 132 (doubled: > 263), other halves never flag.
 	// act : 0xFFFF where the half owns RP rows, 0 where it owns RP-1 (its last register row is transparent)
 	uint32_t fthr = 0xFFFFFFFFu, act = 0, startbits = 0;
+	uint32_t realc = 0, rowsc = 0;               // per half: rows with a real query letter / rows owned (N patch of PAIR)
 	for (int h = 0; h < 2; h++) {
 		const int v = 128 * a.tile + 2 * lane + h;        // global virtual lane
 		int row0, rows_v;
 		lane_rows(v, a.seg_len16, a.vs, &row0, &rows_v);
+		const int real = a.m - row0 < 0 ? 0 : (a.m - row0 > rows_v ? rows_v : a.m - row0);
+		realc |= (uint32_t)real << (16 * h); rowsc |= (uint32_t)rows_v << (16 * h);
 		if (v % a.vs == 0 && v > 0) { fthr = (fthr & ~(0xFFFFu << (16 * h))) | (263u << (16 * h)); startbits |= 0xFFFFu << (16 * h); }
 		if (rows_v == RP) act |= 0xFFFFu << (16 * h);
 	}
@@ -234,9 +241,15 @@ __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves
 				recv_cm = vshift(cm, (int)(by << 16)); recv_fp = vshift(fpo, (int)(by & 0xffff0000u));
 			}
 			const int t_lo = tc & 0xff, t_hi = (tc >> 16) & 0xff;
-			// PAIR: byte offset of the pair's rows = t_lo * 5 * PAIR_STRIDE + t_hi * PAIR_STRIDE + lane offset: one v_dot2_u32_u16
-			const uint8_t* pa = PAIR ? prof + __builtin_amdgcn_udot2(__builtin_bit_cast(v2u, tc), (v2u){ 5 * PAIR_STRIDE, PAIR_STRIDE }, (unsigned)pl_off, false)
-			                         : pl + t_lo * SCAN_CODE_STRIDE;
+			// PAIR: byte offset of the pair's rows = min(t_lo, 3) * 4 * PAIR_STRIDE + min(t_hi, 3) * PAIR_STRIDE + lane offset (one
+			// v_dot2_u32_u16), or pair 16 when both halves hold N
+			const v2u tcv = __builtin_bit_cast(v2u, tc);
+			const v2u isn = __builtin_elementwise_sub_sat(tcv, (v2u){ 3, 3 });            // 1 where the half holds N (code 4)
+			const uint8_t* pa;
+			if constexpr (PAIR) {
+				const unsigned off = __builtin_amdgcn_udot2(__builtin_elementwise_min(tcv, (v2u){ 3, 3 }), (v2u){ 4 * PAIR_STRIDE, PAIR_STRIDE }, (unsigned)pl_off, false);
+				pa = prof + (to_int(isn) == 0x00010001 ? (unsigned)(16 * PAIR_STRIDE + pl_off) : off);
+			} else pa = pl + t_lo * SCAN_CODE_STRIDE;
 			const uint8_t* pb = pl + t_hi * SCAN_CODE_STRIDE + 48;      // (!PAIR only)
 			const int hdiag0 = recv_h_last;           // H[i0-1][c-1]
 			recv_h_last = recv_h;
@@ -249,6 +262,26 @@ __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves
 			for (int g = 0; g < NLOAD; g++) {
 				PA[g] = *reinterpret_cast<const v4i*>(pa + 16 * g);
 				if constexpr (!PAIR) PB[g] = *reinterpret_cast<const v4i*>(pb + 16 * g); else PB[g] = PA[g];
+			}
+			if constexpr (PAIR) {
+				// exactly one half on N: that half was read from the rows of A; N scores -4 (doubled: -8) against every real row,
+				// 0 against the pad rows, and the rows beyond the half's share stay dead
+				const v2u mixed = isn ^ (v2u){ (unsigned short)(to_int(isn) >> 16), (unsigned short)to_int(isn) };   // isn.lo != isn.hi, both halves
+				if (__builtin_amdgcn_ballot_w64(to_int(mixed) != 0) != 0ull) {
+					const v2u nmask = ((v2u){ 0, 0 } - isn) & ((v2u){ 0, 0 } - mixed);
+					// an N column scores the same against every real query row (-4 in stage 2, -1 in the stage-1 alphabet), doubled
+					const unsigned short nv = (unsigned short)(2 * a.score[4 * 5 + 0]);
+					const v2u nval = (v2u){ nv, nv };
+#pragma unroll
+					for (int r = 0; r < RP; r++) {
+						const v2u rr = (v2u){ (unsigned short)r, (unsigned short)r };
+						const v2u isreal = __builtin_elementwise_min(__builtin_elementwise_sub_sat(u_fromi((int)realc), rr), (v2u){ 1, 1 });
+						const v2u islive = __builtin_elementwise_min(__builtin_elementwise_sub_sat(u_fromi((int)rowsc), rr), (v2u){ 1, 1 });
+						const v2u nsc = (isreal * nval) | ((islive - (v2u){ 1, 1 }) & (v2u){ (unsigned short)SCAN_DEAD, (unsigned short)SCAN_DEAD });
+						const int g = r >> 2, k = r & 3;
+						PA[g][k] = (int)(((uint32_t)PA[g][k] & ~(uint32_t)to_int(nmask)) | ((uint32_t)to_int(nsc) & (uint32_t)to_int(nmask)));
+					}
+				}
 			}
 			auto score_of = [&](int r) -> int {
 				const int g = r / ROWS_PER_LOAD, k = r % ROWS_PER_LOAD;
