@@ -224,7 +224,7 @@ def main():
             "phase_wall_s": {k: round(agg[k], 3) for k in ("t_stage1_s", "t_stage2_s", "t_stage3_s", "t_host_s", "t_total_s")},
             "kernel_ms": {KERNEL_NAMES[i]: round(kms[i], 2) for i in range(7)},
             "kernel_launches": {KERNEL_NAMES[i]: int(agg["kernel_launches"][i]) for i in range(7)},
-            "counts": {k: int(agg[k]) for k in ("segments", "units", "candidates", "align_calls", "hazard_units", "rev_exact", "exact_replays",
+            "counts": {k: int(agg[k]) for k in ("segments", "units", "candidates", "align_calls", "hazard_units", "rev_exact", "exact_replays", "tries_skipped",
                                                 "align_word_reruns", "stage2_overflow_units")},
             "roofline": kernel_roofline(0),
             "roofline_stage3": kernel_roofline(2),

@@ -64,7 +64,7 @@ class ScanStats(C.Structure):
                 ("t_stage1_s", C.c_double), ("t_stage2_s", C.c_double), ("t_stage3_s", C.c_double), ("t_host_s", C.c_double),
                 ("kernel_ms", C.c_double * 8), ("kernel_launches", C.c_int64 * 8), ("cells_stage1", C.c_int64),
                 ("cells_stage2", C.c_int64), ("cells_stage3", C.c_int64), ("hazard_units", C.c_int64), ("rev_exact", C.c_int64),
-                ("exact_replays", C.c_int64)]
+                ("exact_replays", C.c_int64), ("tries_skipped", C.c_int64)]
 
 
 class _Result(C.Structure):

@@ -1213,6 +1213,8 @@ int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t*
 				for (const WindowProb& w : W) st.cells_stage3 += (int64_t)E->m * w.len;
 				std::vector<FwdOut> fo;
 				rc = run_fwd_both(E, B, W, fo, &st.align_word_reruns); if (rc) return rc;
+				std::vector<int> fwd_score(fo.size());
+				for (size_t i = 0; i < fo.size(); i++) fwd_score[i] = fo[i].score;
 				{
 					// score >= 148: the REVERSE pass (its own stripe geometry) could hit Q2 -> exact reverse pass now,
 					// so that sw_score = min(forward, reverse) is known before the decision
@@ -1232,7 +1234,14 @@ int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t*
 					}
 					x.fsel = f;                                                                        // "last tried" so far
 					if (f.score >= x.c.score) { x.flag = 1; x.done = 1; continue; }                    // fastsim.h:218-221
-					if (f.score > x.fbest.score && f.ref_end == x.cut - 1) { x.fbest = f; x.bestcut = x.cut; x.flag = 2; }   // :222-235
+					if (f.score > x.fbest.score && f.ref_end == x.cut - 1) {                           // :222-235
+						x.fbest = f; x.bestcut = x.cut; x.flag = 2;
+						// The windows of the later tries are suffixes of this one (same last column, shorter), so their scores
+						// cannot exceed this forward score: no later try is accepted (this one was not) and none can replace
+						// the best one, which needs a strictly larger score.  The reference still runs them; their results are
+						// never used.  (Not when the exact reverse pass lowered this try's score below its forward score.)
+						if (f.score == fwd_score[i]) { x.done = 1; st.tries_skipped += 3 - it; }
+					}
 				}
 			}
 			// the chosen try of every candidate -> reverse pass + traceback
@@ -1478,7 +1487,7 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 			st.align_calls += x.align_calls; st.align_word_reruns += x.align_word_reruns; st.stage2_overflow_units += x.stage2_overflow_units;
 			st.stage1_word_reruns += x.stage1_word_reruns; st.logical_cells += x.logical_cells; st.t_stage1_s += x.t_stage1_s;
 			st.t_stage2_s += x.t_stage2_s; st.t_stage3_s += x.t_stage3_s; st.t_host_s += x.t_host_s; st.cells_stage1 += x.cells_stage1;
-			st.cells_stage2 += x.cells_stage2; st.cells_stage3 += x.cells_stage3; st.hazard_units += x.hazard_units; st.rev_exact += x.rev_exact; st.exact_replays += x.exact_replays;
+			st.cells_stage2 += x.cells_stage2; st.cells_stage3 += x.cells_stage3; st.hazard_units += x.hazard_units; st.rev_exact += x.rev_exact; st.exact_replays += x.exact_replays; st.tries_skipped += x.tries_skipped;
 			drain_timed(ws[wi]);
 			for (int k = 0; k < 8; k++) { st.kernel_ms[k] += ws[wi]->kernel_ms[k]; st.kernel_launches[k] += ws[wi]->kernel_launches[k]; }
 		}

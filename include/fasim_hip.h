@@ -112,6 +112,7 @@ typedef struct fasim_scan_stats {
 	int64_t hazard_units;               /* units re-run by the stripe-faithful kernel (possible Q2)  */
 	int64_t rev_exact;                  /* window tries whose reverse pass ran on the stripe-faithful kernel */
 	int64_t exact_replays;              /* candidates replayed try by try on the stripe-faithful kernels */
+	int64_t tries_skipped;              /* window tries of the reference whose result cannot matter and that were not run */
 } fasim_scan_stats;
 
 typedef struct fasim_result {
