@@ -1219,7 +1219,14 @@ int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t*
 					// score >= 148: the REVERSE pass (its own stripe geometry) could hit Q2 -> exact reverse pass now,
 					// so that sw_score = min(forward, reverse) is known before the decision
 					std::vector<int> rv;
-					for (size_t i = 0; i < fo.size(); i++) if (!fo[i].flags && fo[i].score >= 148 && fo[i].score < 255 - BIAS) rv.push_back((int)i);
+					// ... but only for the tries whose alignment can still be chosen: a try that is accepted by its forward score,
+					// one that would become the best try (alignment ends in the window's last column), or the last try.  Any
+					// other try is neither accepted nor remembered, whatever its reverse pass returns.
+					for (size_t i = 0; i < fo.size(); i++) {
+						if (fo[i].flags || fo[i].score < 148 || fo[i].score >= 255 - BIAS) continue;
+						const CandState& x = cs[who[i]];
+						if (fo[i].score >= x.c.score || fo[i].ref_end == x.cut - 1 || it == 3) rv.push_back((int)i);
+					}
 					rc = run_rev_exact(E, B, W, fo, rv); if (rc) return rc;
 					st.rev_exact += (int64_t)rv.size();
 				}
@@ -1228,6 +1235,8 @@ int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t*
 					const FwdOut& f = fo[i];
 					// flag 1: the forward pass may hit Q2 (or the exact reverse pass was unusable); scores >= 251 go through
 					// the reference's 16-bit kernels: both are replayed on the stripe-faithful path
+					const bool can_be_chosen = f.score >= x.c.score || f.ref_end == x.cut - 1 || it == 3;
+					if (!can_be_chosen && !(f.flags & 1)) { x.fsel = f; continue; }     // neither accepted nor remembered
 					if ((f.flags & 1) || (!(f.flags & 6) && f.score >= 148)) {
 						if (g_prof.on) { if (f.flags & 1) g_prof.add(8 + it, "exact: forward winner tainted / reverse unusable (count)", 1e-6); else g_prof.add(12, "exact: score >= 148 without exact reverse (count)", 1e-6); }
 						x.exact = 1; x.done = 1; continue;
