@@ -6,7 +6,7 @@
 //
 // Parity status: PINNED.  Every function below is checked against the reference
 // implementation compiled from /root/reference (oracle/_ref/ref_probe, oracle/_ref/fasim_ref)
-// and against the golden fixtures those produced (tests/golden/, tools/make_golden.py).
+// and against the golden fixtures those produced (tests/golden/, tests/golden/make_golden.py).
 #ifndef FASIM_ORACLE_H
 #define FASIM_ORACLE_H
 

@@ -4,7 +4,7 @@
 // sources *where they lie* (-I/root/reference, linking ssw_cpp.cpp / sswNew.cpp from
 // there; see oracle/Makefile).  Nothing from the reference is copied into this repo;
 // the resulting binary lives in oracle/_ref/ (git-ignored) and is used to
-//   (1) generate the golden fixtures under tests/golden/ (tools/make_golden.py), and
+//   (1) generate the golden fixtures under tests/golden/ (tests/golden/make_golden.py), and
 //   (2) validate oracle/fasim_oracle.cpp and the HIP path on arbitrary seeded inputs.
 //
 // It calls the reference's own entry points for every stage of the hot path:

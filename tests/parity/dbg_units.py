@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Debug aid (GPU box): per-unit stage-1/2 summary of the systolic scan (FASIM_DEBUG_UNITS=1) against a golden scan
-fixture.    python tools/dbg_units.py demo.scan.gz testDNA.fa"""
+fixture.    python tests/parity/dbg_units.py demo.scan.gz testDNA.fa"""
 import os
 import re
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import helpers  # noqa: E402
 

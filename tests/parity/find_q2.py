@@ -2,7 +2,7 @@
 """Locate (segment, encoding) units in which the reference's signed lazy-F exit (Q2) changes the column maxima.
 Uses the oracle twice per unit (faithful / unsigned exit).  Test tooling only."""
 import ctypes, os, sys, concurrent.futures as cf
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import synth, helpers
 

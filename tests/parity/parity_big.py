@@ -2,9 +2,9 @@
 """Large parity run on the GPU box: our `fasim` CLI (HIP path) against the compiled reference CLI
 (oracle/_ref/fasim_ref) on the same synthetic FASTA; compares the -TFOsorted files byte for byte.
 
-    python tools/parity_big.py random 1000000 12345
-    python tools/parity_big.py planted 500000 4242 -lg 40
-    FASIM_PARITY_RNA=tests/golden/MALAT1.fa python tools/parity_big.py planted 1000000 7    (another query)
+    python tests/parity/parity_big.py random 1000000 12345
+    python tests/parity/parity_big.py planted 500000 4242 -lg 40
+    FASIM_PARITY_RNA=tests/golden/MALAT1.fa python tests/parity/parity_big.py planted 1000000 7    (another query)
 """
 import hashlib
 import os
@@ -14,7 +14,7 @@ import sys
 import tempfile
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import synth  # noqa: E402
 

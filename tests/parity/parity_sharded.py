@@ -4,7 +4,7 @@ segment boundaries (multiples of 4900 nt, each slice = whole 5000-nt segments of
 through our `fasim` CLI (HIP path, one after the other) and through the compiled reference CLI (oracle/_ref/fasim_ref,
 single-threaded, all slices side by side on the box's cores), and the -TFOsorted / -TFOclass files are compared byte
 for byte.
-    python tools/parity_sharded.py [total_mb=50] [slices=13]"""
+    python tests/parity/parity_sharded.py [total_mb=50] [slices=13]"""
 import hashlib
 import os
 import shutil
@@ -13,7 +13,7 @@ import sys
 import tempfile
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import synth  # noqa: E402
 

@@ -1,5 +1,5 @@
 """The CPU restatement (oracle/) against the reference's own outputs (tests/golden/, made by
-tools/make_golden.py from the compiled reference).  CPU only; pins the oracle."""
+tests/golden/make_golden.py from the compiled reference).  CPU only; pins the oracle."""
 import os
 
 import pytest

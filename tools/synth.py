@@ -1,4 +1,4 @@
-"""Deterministic synthetic inputs (shared by tests/, bench.py and tools/make_golden.py).
+"""Deterministic synthetic inputs (shared by tests/, bench.py and tests/golden/make_golden.py).
 
 splitmix64 -> 2 bits per base, 32 bases per 64-bit word, so the same sequence can be regenerated
 anywhere (the C++ driver implements the same generator: fasim-longtarget_amd/csrc/synth.hpp).
