@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
 
-Workload (BASELINE.json configs[1]): H19 (2 812 nt, tests/golden/H19.fa) x synthetic uniform-random DNA
+Default workload (BASELINE.json configs[1]): H19 (2 812 nt, tests/golden/H19.fa) x synthetic uniform-random DNA
 (splitmix64 seed 12345 + rank, `--dna-mb` million nt, default 50) with the reference's default parameters:
 10 205 segments x 48 rule encodings = 489 840 work units per 50 Mb.  One STEP = one complete pass of the hot
 path over that record: stage-1 max score, stage-2 column maxima, candidate picking, every window alignment
@@ -12,8 +12,19 @@ with traceback, triplex records -- i.e. everything fasim_scan() does.  The DNA r
 the timed region and stays resident in HBM.  With N ranks every rank scans its own record (weak scaling,
 no data-path collective) and the records are gathered to rank 0 over RCCL inside the timed region.
 
+Other workloads (second bench lines, parity-test configurations at scale):
+    --dna genome|planted   chromosome-like record (tools/synth.py genome_like, upper-cased) / lncRNA pre-images planted
+    --lncrnas K            BASELINE config 4: K synthetic 3 000-nt lncRNAs (synth.random_rna(3000, k)) scanned as ONE
+                           batch over the resident record (fasim_scan_queries); records gathered per lncRNA
+    --shard                ONE record of N x dna-mb million nt, sharded over the N ranks by contiguous segment ranges
+                           (the layout of the north star), instead of one record per rank
+
 Prints ONE JSON line (rank 0).  value = logical SW Gcells/s of the whole job =
-sum_ranks(m * sum(len(segment)) * 48) * K / max_rank(time) / 1e9   (SURVEY.md 8(d)).
+sum_ranks(sum_queries(m) * sum(len(segment)) * 48) * K / max_rank(time) / 1e9   (SURVEY.md 8(d)).
+
+Kernel-quality figures ("roofline", "valu", "isolated_kernels") come from an UNTIMED extra pass with ONE batch in
+flight, so that HIP-event durations are exclusive: in the timed steps ten batches share the GPU and per-kernel
+durations overlap (their sum exceeds the step time; they are reported as "kernel_ms_overlapped" for reference only).
 """
 import argparse
 import json
@@ -34,48 +45,96 @@ import __graft_entry__ as entry  # noqa: E402
 import synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
-VALU_PEAK_TOPS = 78.6           # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz: plain VALU, one lane-instruction per lane per clock
-# The DP kernels consist of packed 16-bit ops (v_pk_add_i16 / v_pk_max_* / v_pk_sub_u16).  Measured with
-# rocprofv3 --pmc on k_scan and k_align_fwd (profiles/r01_sq_counters.txt): SQ_INSTS_VALU == SQ_BUSY_CU_CYCLES, i.e. one
-# wave64 VALU instruction per CU clock = 4 clocks per instruction and SIMD with four waves resident: the packed ops
-# issue at half the plain rate, and at that rate the kernels sit at the issue limit.
-VALU_PK16_PEAK_TOPS = 39.3      # 256 CU x 4 SIMD x 16 lanes x 2.4 GHz (lane-instructions/s of packed 16-bit ops)
+# VALU issue peak for the instruction class the DP kernels are made of.  MI355X_MICROARCH.md: a wave64 VALU instruction
+# issues over 2 clocks on a SIMD-32; profiles/r02_valu_issue_bench.txt (source tools/valu_issue_bench.hip, run on the
+# same box) measures the packed 16-bit integer ops (v_pk_add_i16 / v_pk_max_i16 / v_pk_sub_u16 clamp) at HALF that rate:
+# 4 clocks per wave64 instruction and SIMD.  Peak in packed lane-instructions per second at the 2.4 GHz peak clock
+# (the chip runs 1.9-2.3 GHz under load, so 100 % is not reachable):
+CLOCK_GHZ = 2.4
+VALU_PK16_PEAK_TOPS = 256 * 4 * 64 / 4 * CLOCK_GHZ / 1e3     # = 39.3 T packed lane-instructions/s (2 cells each)
+VALU_PLAIN_PEAK_TOPS = 256 * 4 * 64 / 2 * CLOCK_GHZ / 1e3    # = 78.6 T: the guide's plain-VALU rate (what fp32 code gets)
 KERNEL_NAMES = ["k_scan (fused stage 1+2)", "k_striped<PRE|MAX1> (stage 1/2 hazard re-runs)", "k_align_fwd (stage 3 forward)",
                 "k_finish_lds (reverse pass + traceback)", "k_encode/k_scan_post/k_hits/k_build_stream",
                 "k_striped<ALIGN|REV> (stage 3 exact replays)", "k_finish/k_banded (global scratch)", "-"]
+# packed VALU instructions per DP cell of the variants that are launched by default:
+#   k_scan<RP,PAIR=false>: perm, add, 3 x max, 3 x sat-sub, 2 x max = 10 per row pair = 5.0 per cell
+#   k_align_fwd<RP,TAINT,PAIR=false>: the same + the row-key OR = 11 per row pair = 5.5 per cell
+def _env_on(name):
+    return os.environ.get(name, "0").strip() not in ("", "0")
 
 
-def cpu_baseline(rna_path, m, sample_nt, seed):
-    """The reference's own SSE2 binary (oracle/_ref/fasim_ref, built from /root/reference by oracle/Makefile)
-    on the first `sample_nt` nt of the same synthetic record, 1 thread (the reference is single-threaded).
-    Falls back to the oracle port when the reference binary did not travel."""
-    ref = os.path.join(ROOT, "oracle", "_ref", "fasim_ref")
-    dna = synth.random_dna(sample_nt, seed)
-    nseg_cells = sum(min(5000, sample_nt - s) for s in range(0, sample_nt, 4900))
-    cells = m * nseg_cells * 48
-    wd = tempfile.mkdtemp(prefix="fasim_cpu_")
+OPS_PER_CELL = {"k_scan": 4.5 if _env_on("FASIM_SCAN_PAIR") else 5.0, "k_align_fwd": 5.0 if _env_on("FASIM_FWD_PAIR") else 5.5}
+
+
+def host_cores():
+    """cores this process may really use: scheduler affinity, capped by the cgroup CPU quota when there is one"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
-        synth.write_fasta(os.path.join(wd, "sample.fa"), f"syn|chrS|1-{sample_nt}", dna)
-        shutil.copyfile(rna_path, os.path.join(wd, "H19.fa"))
-        os.makedirs(os.path.join(wd, "out"))
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
+def _ref_run(wd, name, dna, rna_path, m, cells_out):
+    """one reference process on one slice (the reference is single-threaded); returns the Popen"""
+    d = os.path.join(wd, name)
+    os.makedirs(os.path.join(d, "out"))
+    synth.write_fasta(os.path.join(d, "sample.fa"), f"syn|chrS|1-{len(dna)}", dna)
+    shutil.copyfile(rna_path, os.path.join(d, "rna.fa"))
+    cells_out.append(m * sum(min(5000, len(dna) - s) for s in range(0, len(dna), 4900)) * 48)
+    ref = os.path.join(ROOT, "oracle", "_ref", "fasim_ref")
+    return subprocess.Popen([ref, "-f1", "sample.fa", "-f2", "rna.fa", "-O", "out/"], cwd=d, stdout=subprocess.DEVNULL,
+                            stderr=subprocess.DEVNULL)
+
+
+def cpu_baseline(rna_path, m, slices):
+    """The reference's own SSE2 binary (oracle/_ref/fasim_ref, built from /root/reference by oracle/Makefile) on slices
+    of the same kind of synthetic record: (a) ONE process on slices[0] = the 1-thread figure (the reference is
+    single-threaded); (b) len(slices) processes side by side, one slice each = the all-core figure.
+    Falls back to the oracle port when the reference binary did not travel."""
+    sample_nt, cores = len(slices[0]), len(slices)
+
+    def make_dna(_n, k):
+        return slices[k]
+    ref = os.path.join(ROOT, "oracle", "_ref", "fasim_ref")
+    wd = tempfile.mkdtemp(prefix="fasim_cpu_")
+    out = {}
+    try:
         if os.access(ref, os.X_OK):
+            cells = []
             t0 = time.perf_counter()
-            subprocess.run([ref, "-f1", "sample.fa", "-f2", "H19.fa", "-O", "out/"], cwd=wd, check=True,
-                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-            dt = time.perf_counter() - t0
-            kind = "reference"
+            assert _ref_run(wd, "one", make_dna(sample_nt, 0), rna_path, m, cells).wait() == 0
+            dt1 = time.perf_counter() - t0
+            out = {"value": round(cells[0] / dt1 / 1e9, 4), "unit": "Gcells/s", "cores": 1, "kind": "reference",
+                   "sample": f"query x first {sample_nt} nt of the same synthetic record, default parameters, {dt1:.1f} s wall",
+                   "mbp_per_s": round(sample_nt / dt1 / 1e6, 5)}
+            if cores > 1:
+                cells = []
+                t0 = time.perf_counter()
+                procs = [_ref_run(wd, f"p{k}", make_dna(sample_nt, k), rna_path, m, cells) for k in range(cores)]
+                assert all(p.wait() == 0 for p in procs)
+                dtn = time.perf_counter() - t0
+                out["all_cores"] = {"value": round(sum(cells) / dtn / 1e9, 3), "unit": "Gcells/s", "cores": cores,
+                                    "sample": f"{cores} reference processes side by side, one {sample_nt}-nt slice each, {dtn:.1f} s wall",
+                                    "mbp_per_s": round(sample_nt * cores / dtn / 1e6, 5)}
         else:
             subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"], check=True)
             exe = os.path.join(ROOT, "oracle", "_build", "fasim_oracle")
+            dna = make_dna(sample_nt, 0)
+            synth.write_fasta(os.path.join(wd, "sample.fa"), f"syn|chrS|1-{sample_nt}", dna)
+            shutil.copyfile(rna_path, os.path.join(wd, "rna.fa"))
+            cells = m * sum(min(5000, sample_nt - s) for s in range(0, sample_nt, 4900)) * 48
             t0 = time.perf_counter()
-            subprocess.run([exe, "tfosorted", "H19.fa", "sample.fa"], cwd=wd, check=True, stdout=subprocess.DEVNULL)
-            dt = time.perf_counter() - t0
-            kind = "port"
+            subprocess.run([exe, "tfosorted", "rna.fa", "sample.fa"], cwd=wd, check=True, stdout=subprocess.DEVNULL)
+            dt1 = time.perf_counter() - t0
+            out = {"value": round(cells / dt1 / 1e9, 4), "unit": "Gcells/s", "cores": 1, "kind": "port",
+                   "sample": f"oracle port, query x first {sample_nt} nt, {dt1:.1f} s wall", "mbp_per_s": round(sample_nt / dt1 / 1e6, 5)}
     finally:
         shutil.rmtree(wd, ignore_errors=True)
-    return {"value": round(cells / dt / 1e9, 4), "unit": "Gcells/s", "cores": 1, "kind": kind,
-            "sample": f"H19 x first {sample_nt} nt of the same synthetic record, default parameters, {dt:.1f} s wall",
-            "mbp_per_s": round(sample_nt / dt / 1e6, 5)}
+    return out
 
 
 def main():
@@ -84,7 +143,11 @@ def main():
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--dna-mb", type=float, default=50.0, help="million nt of synthetic DNA per rank (default 50)")
+    ap.add_argument("--dna", choices=["random", "genome", "planted"], default="random")
+    ap.add_argument("--lncrnas", type=int, default=0, help="K > 0: K synthetic 3 kb lncRNAs as one batch (BASELINE config 4)")
+    ap.add_argument("--shard", action="store_true", help="one record of gpus x dna-mb, sharded by contiguous segment ranges")
     ap.add_argument("--cpu-sample-nt", type=int, default=250000)
+    ap.add_argument("--cpu-cores", type=int, default=0, help="processes of the all-core CPU baseline (0 = all cores this process may use, at most 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses device 0 (needs --backend gloo)")
@@ -113,18 +176,41 @@ def main():
     mod = entry.load()
     eng = mod.Engine(local)
     rna_path = os.path.join(ROOT, "tests", "golden", "H19.fa")
-    _, rna = synth.read_fasta(rna_path)
-    eng.set_query(rna)
+    _, h19 = synth.read_fasta(rna_path)
+    rnas = [synth.random_rna(3000, k + 1) for k in range(args.lncrnas)] if args.lncrnas > 0 else [h19]
+    m_sum = sum(len(r) for r in rnas)
+
+    def make_dna(n, k):
+        """the k-th record of the workload (k = rank in the weak-scaling layout)"""
+        if args.dna == "random":
+            return mod.synth_dna(n, 12345 + k)
+        if args.dna == "genome":
+            return synth.genome_like(n, 12345 + k, soft_mask=False)
+        return synth.planted_dna(n, 12345 + k, rnas[0])
+
     n = int(args.dna_mb * 1e6)
-    dna = mod.synth_dna(n, 12345 + rank)
-    eng.load_dna(dna)                      # resident in HBM before the timed region
     p = mod.default_params()
+    if args.shard:
+        dna = make_dna(n * world, 0)                       # every rank generates the same record and scans its shard of it
+        seg_first, seg_count = mod.shard_segments(mod.segment_count(len(dna), p), rank, world)
+    else:
+        dna = make_dna(n, rank)
+        seg_first, seg_count = 0, -1
+    eng.load_dna(dna)                      # resident in HBM before the timed region
+    if args.lncrnas <= 0:
+        eng.set_query(h19)
 
     def step():
-        res = eng.scan(None, p)
-        # the path's one exchange step: gather every rank's records on rank 0 (RCCL over xGMI)
-        merged = mod.gather_results(res, dist, rank, world, xdev)
-        return res, (merged.count if merged is not None else 0)
+        if args.lncrnas > 0:
+            res = eng.scan_queries(rnas, None, p, seg_first, seg_count)
+        else:
+            res = [eng.scan(None, p, seg_first, seg_count)]
+        # the path's one exchange step: gather every rank's records on rank 0 (RCCL over xGMI), per lncRNA
+        nrec = 0
+        for r in res:
+            merged = mod.gather_results(r, dist, rank, world, xdev)
+            nrec += merged.count if merged is not None else 0
+        return res, nrec
 
     def sync():
         torch.cuda.synchronize()
@@ -140,15 +226,17 @@ def main():
     nrec = 0
     for _ in range(args.steps):
         res, nrec = step()
-        st = res.stats
-        if agg is None:
-            agg = {k: (list(v) if isinstance(v, list) else v) for k, v in st.items()}
-        else:
-            for k, v in st.items():
-                if isinstance(v, list):
-                    agg[k] = [a + b for a, b in zip(agg[k], v)]
-                else:
-                    agg[k] += v
+        for r in res:
+            st = r.stats
+            if agg is None:
+                agg = {k: (list(v) if isinstance(v, list) else v) for k, v in st.items()}
+            else:
+                for k, v in st.items():
+                    if isinstance(v, list):
+                        agg[k] = [a + b for a, b in zip(agg[k], v)]
+                    else:
+                        agg[k] += v
+        del res
     sync()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=xdev)
@@ -159,50 +247,64 @@ def main():
     tmax = float(tmax.item())
     total_cells = float(cells.item())
 
-    # untimed extra pass for the kernel-quality figures: ONE batch in flight, so HIP-event durations are those of a
-    # kernel that has the GPU to itself (in the timed steps six batches share it and every duration is stretched)
+    # untimed extra pass for the kernel-quality figures: ONE batch in flight, so every HIP-event duration is that of a
+    # kernel that has the GPU to itself (exclusive); first lncRNA of the workload, first <= 1024 segments of the shard
     iso = None
     if rank == 0:
+        eng.set_query(rnas[0])
         eng.set_option("workers", 1)
         eng.set_option("seg_batch", 1024)
-        nseg_iso = min(1024, mod.segment_count(n, p))
-        iso = eng.scan(None, p, 0, nseg_iso).stats
+        total_seg = mod.segment_count(len(dna), p)
+        have = seg_count if seg_count >= 0 else total_seg
+        iso = eng.scan(None, p, seg_first, min(1024, have)).stats
         eng.set_option("workers", 0)
         eng.set_option("seg_batch", 0)
 
     if rank == 0:
-        m = len(rna)
+        m = len(rnas[0])
         units_per_step = agg["units"] / args.steps
         kms = agg["kernel_ms"]
-        n_avg = agg["cells_stage2"] / max(1, agg["units"]) / m        # mean segment length
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        except Exception:
-            pmc = {}
+        ik, il = iso["kernel_ms"], iso["kernel_launches"]
+        n_avg = iso["cells_stage2"] / max(1, iso["units"]) / m        # mean segment length of the isolated pass
 
         def kernel_roofline(idx):
-            """HBM roofline of one of the two DP kernels: algorithmic bytes per launch / HIP-event launch duration."""
-            launches_k = max(1, agg["kernel_launches"][idx])
-            avg = kms[idx] / launches_k
-            if idx == 0:   # k_scan, per unit: segment codes in (n) + u16 column maxima out (2n); the profile is LDS-resident
-                per_item, items, key = 3 * n_avg, agg["units"] + agg["stage1_word_reruns"], "k_scan"
+            """HBM roofline of one of the two DP kernels from the isolated pass: algorithmic bytes per launch / exclusive
+            HIP-event duration per launch (recorded on the stream the kernel is launched on)."""
+            launches_k = max(1, il[idx])
+            avg = ik[idx] / launches_k
+            if idx == 0:   # k_scan, per unit (SURVEY 8(d)): segment codes in (n) + u16 column maxima out (2n) + int8 profile in (5m)
+                items = iso["units"] + iso["stage1_word_reruns"]
+                per_item = 3 * n_avg + 5 * m
+                alt = {"algorithmic_bytes_per_launch_3n_only": int(3 * n_avg * items / launches_k)}
             else:          # k_align_fwd, per window try: L + 2 stream bytes in, 16-byte descriptor in, 24-byte result out
-                calls = max(1, agg["align_calls"])
-                per_item, items, key = agg["cells_stage3"] / m / calls + 2 + 16 + 24, calls + agg["align_word_reruns"], "k_align_fwd"
+                calls = max(1, iso["align_calls"])
+                items = calls + iso["align_word_reruns"]
+                per_item = iso["cells_stage3"] / m / calls + 2 + 16 + 24
+                alt = {}
             alg = per_item * items / launches_k
-            tr = pmc.get(key, {}).get("hbm_bytes_per_item")
-            return {"bound": "hbm", "kernel": KERNEL_NAMES[idx], "achieved": round(alg / (avg * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
-                    "traffic": int(tr * items / launches_k) if tr else None, "avg_launch_ms": round(avg, 3), "launches": int(launches_k),
-                    "algorithmic_bytes_per_launch": int(alg),
-                    "note": "integer DP is VALU-bound by construction; see valu"}
+            d = {"bound": "hbm", "kernel": KERNEL_NAMES[idx], "achieved": round(alg / (avg * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS,
+                 "unit": "GB/s", "frac": round(alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+                 "traffic_note": "HBM bytes from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE are collected in separate profiled runs "
+                                 "(tools/pmc_traffic.py) and kept under profiles/; nothing is read from there at bench time",
+                 "avg_launch_ms": round(avg, 3), "launches": int(launches_k), "algorithmic_bytes_per_launch": int(alg),
+                 "items_per_launch": int(items / launches_k), "source": "isolated pass: one batch in flight, exclusive HIP-event durations",
+                 "note": "integer DP is VALU-bound by construction (SURVEY 8(d)); see valu"}
+            d.update(alt)
+            return d
 
-        # dominant kernel: k_scan (fused stage 1+2: most DP cells; its time and k_align_fwd's are within a few percent)
-        dom = 0
-        launches = max(1, agg["kernel_launches"][dom])
-        avg_ms = kms[dom] / launches
-        cells_dom, ops_per_cell = agg["cells_stage2"], 4.5
-        traffic_per_unit = pmc.get("k_scan", {}).get("hbm_bytes_per_unit")
+        def valu(idx, key, cells_k):
+            t = ik[idx] * 1e-3
+            ops = OPS_PER_CELL[key]
+            return {"kernel": KERNEL_NAMES[idx], "ms": round(ik[idx], 2), "gcells_per_s": round(cells_k / t / 1e9, 1),
+                    "ops_per_cell": ops, "achieved_tops": round(cells_k * ops / t / 1e12, 3),
+                    "peak_tops": round(VALU_PK16_PEAK_TOPS, 1), "frac": round(cells_k * ops / t / 1e12 / VALU_PK16_PEAK_TOPS, 4),
+                    "frac_of_plain_valu_peak": round(cells_k * ops / t / 1e12 / VALU_PLAIN_PEAK_TOPS, 4)}
+
+        executed = agg["cells_stage1"] + agg["cells_stage2"] + agg["cells_stage3"]
+        workload = (f"{args.lncrnas} synthetic 3000-nt lncRNAs (one batch)" if args.lncrnas > 0 else "H19 (2812 nt)") + \
+            f" x synthetic {args.dna} DNA, " + (f"ONE record of {args.dna_mb * world:g} Mb sharded over {world} GPU(s) by contiguous segment ranges"
+                                                if args.shard else f"{args.dna_mb:g} Mb per GPU (seed 12345+rank)") + \
+            ", default parameters, 48 rule encodings, records gathered to rank 0"
         out = {
             "metric": "SW Gcells/s (logical, whole job: stage 1+2+3 of the triplex scan)",
             "value": round(total_cells / tmax / 1e9, 3),
@@ -216,45 +318,52 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": f"H19 (2812 nt) x synthetic {args.dna_mb:g} Mb DNA per GPU (splitmix64 seed 12345+rank), "
-                                   "default parameters, 48 rule encodings, records gathered to rank 0",
-                       "units_per_step_per_gpu": int(units_per_step), "records_rank0": int(nrec)},
-            "mbp_per_s": round(n * world * args.steps / tmax / 1e6, 3),
-            "executed_gcells_per_s": round((agg["cells_stage1"] + agg["cells_stage2"] + agg["cells_stage3"]) / (tmax) / 1e9 * 1.0, 3),
-            "phase_wall_s": {k: round(agg[k], 3) for k in ("t_stage1_s", "t_stage2_s", "t_stage3_s", "t_host_s", "t_total_s")},
-            "kernel_ms": {KERNEL_NAMES[i]: round(kms[i], 2) for i in range(7)},
+            "config": {"workload": workload, "units_per_step_per_gpu": int(units_per_step), "records_rank0": int(nrec),
+                       "lncrnas": len(rnas), "sharded_record": bool(args.shard)},
+            "mbp_per_s_per_lncrna": round(len(dna) * (1 if args.shard else world) * args.steps / tmax / 1e6, 3),
+            "executed_gcells_per_s": round(executed / tmax / 1e9, 3),
+            "executed_cells_per_step": {k: int(agg[k] / args.steps) for k in ("cells_stage1", "cells_stage2", "cells_stage3")},
+            "phase_wall_s_summed_over_batches": {k: round(agg[k], 3) for k in ("t_stage1_s", "t_stage2_s", "t_stage3_s", "t_host_s")},
+            "kernel_ms_overlapped": {KERNEL_NAMES[i]: round(kms[i], 2) for i in range(7)},
             "kernel_launches": {KERNEL_NAMES[i]: int(agg["kernel_launches"][i]) for i in range(7)},
-            "counts": {k: int(agg[k]) for k in ("segments", "units", "candidates", "align_calls", "hazard_units", "rev_exact", "exact_replays", "tries_skipped",
-                                                "align_word_reruns", "stage2_overflow_units")},
+            "counts": {k: int(agg[k]) for k in ("segments", "segments_skipped", "units", "candidates", "align_calls", "hazard_units", "rev_exact",
+                                                "exact_replays", "tries_skipped", "align_word_reruns", "stage2_overflow_units", "stage1_word_reruns")},
+            "per_unit": {"candidates": round(agg["candidates"] / max(1, agg["units"]), 2),
+                         "hazard_units_pct": round(100.0 * agg["hazard_units"] / max(1, agg["units"]), 3),
+                         "overflow_units_pct": round(100.0 * agg["stage2_overflow_units"] / max(1, agg["units"]), 3)},
             "roofline": kernel_roofline(0),
             "roofline_stage3": kernel_roofline(2),
-            "valu": {"kernel": KERNEL_NAMES[dom], "gcells_per_s": round(cells_dom / (kms[dom] * 1e-3) / 1e9, 2),
-                     "ops_per_cell": ops_per_cell, "achieved_tops": round(cells_dom * ops_per_cell / (kms[dom] * 1e-3) / 1e12, 3),
-                     "peak_tops": VALU_PK16_PEAK_TOPS,
-                     "frac": round(cells_dom * ops_per_cell / (kms[dom] * 1e-3) / 1e12 / VALU_PK16_PEAK_TOPS, 4),
-                     "issue_utilisation_measured": 0.99,
-                     "issue_utilisation_source": "profiles/r01_sq_counters.txt: SQ_INSTS_VALU / SQ_BUSY_CU_CYCLES of this kernel with one batch in "
-                                                 "flight (rocprofv3 --pmc), i.e. one wave64 packed op per CU clock = the packed-16 issue limit",
-                     "note": "VALU instructions per DP cell x executed cells / HIP-event time of this kernel family; "
-                             "peak = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz: packed 16-bit VALU ops issue at 4 clocks per wave64 (measured, "
-                             "profiles/r01_sq_counters.txt), half the plain VALU rate; the "
-                             "packed 16-bit kernels process two cells per lane-instruction); kernel times include "
-                             "sharing the GPU with the other batches in flight"},
+            "valu": valu(0, "k_scan", iso["cells_stage2"]),
+            "valu_stage3": valu(2, "k_align_fwd", iso["cells_stage3"]),
+            "valu_note": "packed 16-bit VALU instructions per DP cell x executed cells / EXCLUSIVE HIP-event time (isolated pass); "
+                         "peak = 256 CU x 4 SIMD x 64 lanes / 4 clocks x 2.4 GHz: packed 16-bit integer ops issue at 4 clocks per "
+                         "wave64 (profiles/r02_valu_issue_bench.txt), half the plain VALU rate of the guide; each packed "
+                         "lane-instruction processes two cells",
         }
-        ik = iso["kernel_ms"]
         out["isolated_kernels"] = {
-            "what": f"untimed pass over the first {iso['segments']} segments with ONE batch in flight (kernels run alone)",
-            "units": iso["units"], "align_calls": iso["align_calls"],
-            "k_scan": {"ms": round(ik[0], 2), "gcells_per_s": round(iso["cells_stage2"] / (ik[0] * 1e-3) / 1e9, 1),
-                       "valu_frac": round(iso["cells_stage2"] * 4.5 / (ik[0] * 1e-3) / 1e12 / VALU_PK16_PEAK_TOPS, 4),
-                       "hbm_GBps": round((traffic_per_unit or 0) * iso["units"] / (ik[0] * 1e-3) / 1e9, 2)},
-            "k_align_fwd": {"ms": round(ik[2], 2), "gcells_per_s": round(iso["align_calls"] and iso["cells_stage3"] / (ik[2] * 1e-3) / 1e9, 1),
-                            "valu_frac": round(iso["cells_stage3"] * 5.5 / (ik[2] * 1e-3) / 1e12 / VALU_PK16_PEAK_TOPS, 4)},
-            "k_striped_hazard_reruns_ms": round(ik[1], 2), "k_finish_lds_ms": round(ik[3], 2),
-            "k_striped_exact_replays_ms": round(ik[5], 2), "k_finish_k_banded_global_ms": round(ik[6], 2),
+            "what": f"untimed pass over {iso['segments']} segments with ONE batch in flight (kernels run alone)",
+            "units": iso["units"], "align_calls": iso["align_calls"], "hazard_units": iso["hazard_units"], "rev_exact": iso["rev_exact"],
+            "ms": {KERNEL_NAMES[i]: round(ik[i], 2) for i in range(7)},
+            "dominant_kernel_ms_per_step_equivalent": round(ik[0] * units_per_step / max(1, iso["units"]), 1),
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(rna_path, m, args.cpu_sample_nt, 12345)
+            cores = args.cpu_cores if args.cpu_cores > 0 else host_cores()
+            tmp_rna = None
+            cpu_rna = rna_path
+            if args.lncrnas > 0:
+                tmp_rna = tempfile.NamedTemporaryFile(suffix=".fa", delete=False)
+                tmp_rna.write(b">syn3k_1\n" + rnas[0] + b"\n")
+                tmp_rna.close()
+                cpu_rna = tmp_rna.name
+            nn = args.cpu_sample_nt
+            if args.dna == "random":      # slice 0 = the head of rank 0's record; the others: further records of the same stream family
+                slices = [synth.random_dna(nn, 12345 + 1000 * k) for k in range(cores)]
+            else:
+                big = make_dna(nn * cores, 0)
+                slices = [big[nn * k:nn * (k + 1)] for k in range(cores)]
+            out["cpu_baseline"] = cpu_baseline(cpu_rna, m, slices)
+            if tmp_rna:
+                os.unlink(tmp_rna.name)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

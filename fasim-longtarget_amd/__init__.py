@@ -23,7 +23,6 @@ import os
 # the scan keeps ~10 batches in flight on separate HIP streams; give them more than the runtime's default of four
 # hardware queues (must be in the environment before HIP initialises, i.e. before torch touches the GPU)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-from dataclasses import dataclass
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfasim_hip.so")
@@ -47,13 +46,13 @@ class Alignment(C.Structure):
 
     def cigar_string(self) -> str:
         ops = "MIDNSHP=X"
-        return "".join(f"{c >> 4}{'M' if (c & 15) > 8 else ops[c & 15]}" for c in self.cigar[: self.cigar_len])
+        return "".join(f"{c >> 4}{'M' if (c & 15) > 8 else ops[c & 15]}" for c in self.cigar[: max(0, self.cigar_len)])
 
 
 class Triplex(C.Structure):
     _fields_ = [("stari", C.c_int32), ("endi", C.c_int32), ("starj", C.c_int32), ("endj", C.c_int32), ("strand", C.c_int32),
                 ("reverse", C.c_int32), ("rule", C.c_int32), ("nt", C.c_int32), ("score", C.c_float), ("identity", C.c_float),
-                ("tri_score", C.c_float), ("seg", C.c_int32), ("enc", C.c_int32), ("reserved", C.c_int32),
+                ("tri_score", C.c_float), ("seg", C.c_int32), ("enc", C.c_int32), ("genome_shift", C.c_int32),
                 ("tfo_off", C.c_int64), ("tts_off", C.c_int64)]
 
 
@@ -73,11 +72,15 @@ class _Result(C.Structure):
 
 
 EXPORTS = ["fasim_params_default", "fasim_engine_create", "fasim_engine_destroy", "fasim_last_error", "fasim_set_option", "fasim_set_query",
-           "fasim_calc_score_once", "fasim_ssw_pre_align", "fasim_pick_candidates", "fasim_ssw_align", "fasim_pre_align_batch",
-           "fasim_align_batch", "fasim_encode_unit", "fasim_scan", "fasim_load_dna", "fasim_result_free", "fasim_segment_count",
-           "fasim_tfosorted", "fasim_tfoclass", "fasim_free", "fasim_synth_dna"]
+           "fasim_calc_score_once", "fasim_ssw_pre_align", "fasim_ssw_colmax_word", "fasim_pick_candidates", "fasim_ssw_align", "fasim_pre_align_batch",
+           "fasim_align_batch", "fasim_encode_unit", "fasim_scan", "fasim_scan_queries", "fasim_merge_results", "fasim_rebase_offsets", "fasim_load_dna", "fasim_result_free", "fasim_segment_count",
+           "fasim_tfosorted", "fasim_tfoclass", "fasim_tfosorted_ex", "fasim_tfoclass_ex", "fasim_upper_case", "fasim_free",
+           "fasim_synth_dna",
+           # the reference's own ssw.h ABI (include/ssw.h)
+           "ssw_init", "init_destroy", "ssw_pre_align", "ssw_align", "align_destroy", "encoded_ops"]
 
 _lib = None
+_EMPTY_POOL = C.create_string_buffer(1)
 
 
 def lib():
@@ -110,14 +113,26 @@ def lib():
     L.fasim_scan.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(Params),
                              C.POINTER(C.POINTER(_Result))]
     L.fasim_load_dna.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    L.fasim_scan_queries.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.c_int32, C.c_char_p, C.c_int64,
+                                     C.c_int64, C.c_int64, C.POINTER(Params), C.POINTER(C.POINTER(_Result))]
+    L.fasim_merge_results.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                                      C.c_int32, C.POINTER(C.POINTER(_Result))]
+    L.fasim_rebase_offsets.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+    L.fasim_ssw_colmax_word.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(C.c_int32)]
     L.fasim_result_free.argtypes = [C.POINTER(_Result)]
     L.fasim_result_free.restype = None
     L.fasim_segment_count.argtypes = [C.c_int64, C.POINTER(Params)]
     L.fasim_segment_count.restype = C.c_int64
-    L.fasim_tfosorted.argtypes = [C.c_void_p, C.c_int64, C.c_char_p, C.c_int64, C.c_char_p, C.c_int64, C.POINTER(Params),
+    L.fasim_tfosorted.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_char_p, C.c_int64, C.POINTER(Params),
                                   C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
     L.fasim_tfoclass.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_char_p, C.c_int64, C.c_int64, C.c_char_p,
                                  C.POINTER(Params), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    L.fasim_tfosorted_ex.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_char_p, C.c_int64, C.POINTER(Params),
+                                     C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    L.fasim_tfoclass_ex.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_char_p, C.c_int64, C.c_int64, C.c_char_p,
+                                    C.POINTER(Params), C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    L.fasim_upper_case.argtypes = [C.c_void_p, C.c_int64]
+    L.fasim_upper_case.restype = None
     L.fasim_free.argtypes = [C.c_void_p]
     L.fasim_free.restype = None
     L.fasim_synth_dna.argtypes = [C.c_char_p, C.c_int64, C.c_uint64]
@@ -136,42 +151,94 @@ def default_params(**kw) -> Params:
     return p
 
 
-@dataclass
 class ScanResult:
-    """Records of one scan (or of one shard): raw bytes, ready to be gathered across ranks."""
-    recs: bytes          # count * sizeof(Triplex)
-    pool: bytes
-    stats: dict
+    """Records of one scan (or of one shard, or of a merge).  Either a view of a native `fasim_result` (what scan() and
+    merge_results() return: nothing is copied) or two Python byte strings (`ScanResult(recs, pool, stats)`)."""
+
+    def __init__(self, recs: bytes | None = b"", pool: bytes | None = b"", stats: dict | None = None, _native=None, _ext=None):
+        self.stats = stats if stats is not None else {}
+        self._native = _native            # POINTER(_Result) owned by this object
+        self._ext = _ext                  # (recs address, count, pool address, pool_len, owner of that memory)
+        lazy = _native is not None or _ext is not None
+        self._recs = None if lazy else (recs or b"")
+        self._pool = None if lazy else (pool or b"")
+
+    def __del__(self):
+        try:
+            if self._native is not None:
+                lib().fasim_result_free(self._native)
+                self._native = None
+        except Exception:
+            pass
 
     @property
     def count(self) -> int:
-        return len(self.recs) // C.sizeof(Triplex)
+        if self._native is not None or self._ext is not None:
+            return self.pointers()[1]
+        return len(self._recs) // C.sizeof(Triplex)
+
+    @property
+    def pool_len(self) -> int:
+        return self.pointers()[3] if (self._native is not None or self._ext is not None) else len(self._pool)
+
+    @property
+    def recs(self) -> bytes:
+        if self._recs is None:
+            rp, cnt, _, _ = self.pointers()
+            self._recs = C.string_at(rp, cnt * C.sizeof(Triplex)) if cnt else b""
+        return self._recs
+
+    @property
+    def pool(self) -> bytes:
+        if self._pool is None:
+            _, _, pp, plen = self.pointers()
+            self._pool = C.string_at(pp, plen) if plen else b""
+        return self._pool
+
+    def pointers(self):
+        """(recs address, count, pool address, pool_len) for the C-ABI; valid while this object lives."""
+        if self._ext is not None:
+            return self._ext[:4]
+        if self._native is not None:
+            r = self._native.contents
+            return C.cast(r.recs, C.c_void_p).value or 0, int(r.count), C.cast(r.pool, C.c_void_p).value or 0, int(r.pool_len)
+        if getattr(self, "_keep", None) is None:      # created once: earlier pointers must stay valid
+            self._keep = (C.create_string_buffer(self._recs, max(1, len(self._recs))), C.create_string_buffer(self._pool, max(1, len(self._pool))))
+        return C.addressof(self._keep[0]), self.count, C.addressof(self._keep[1]), len(self._pool)
 
     def triplexes(self):
-        arr = (Triplex * self.count).from_buffer_copy(self.recs)
+        recs, pool = self.recs, self.pool
+        arr = (Triplex * self.count).from_buffer_copy(recs)
         out = []
         for t in arr:
-            tfo = self.pool[t.tfo_off:self.pool.index(b"\0", t.tfo_off)]
-            tts = self.pool[t.tts_off:self.pool.index(b"\0", t.tts_off)]
+            tfo = pool[t.tfo_off:pool.index(b"\0", t.tfo_off)]
+            tts = pool[t.tts_off:pool.index(b"\0", t.tts_off)]
             out.append((t.stari, t.endi, t.starj, t.endj, t.strand, t.reverse, t.rule, t.nt, int(t.score),
                         C.c_uint32.from_buffer_copy(C.c_float(t.identity)).value,
                         C.c_uint32.from_buffer_copy(C.c_float(t.tri_score)).value, tfo, tts, t.seg, t.enc))
         return out
 
 
+def _merge_pointers(ptrs):
+    """ptrs: list of (recs address, count, pool address, pool_len) -> native-backed ScanResult (fasim_merge_results)."""
+    L = lib()
+    n = len(ptrs)
+    recs = (C.c_void_p * n)(*[p[0] or None for p in ptrs])
+    counts = (C.c_int64 * n)(*[p[1] for p in ptrs])
+    pools = (C.c_void_p * n)(*[p[2] or None for p in ptrs])
+    plens = (C.c_int64 * n)(*[p[3] for p in ptrs])
+    out = C.POINTER(_Result)()
+    rc = L.fasim_merge_results(recs, counts, pools, plens, n, C.byref(out))
+    if rc != 0:
+        raise FasimError(f"fasim_merge_results failed ({rc}): {L.fasim_last_error(None).decode()}")
+    return ScanResult(stats={}, _native=out)
+
+
 def merge_results(parts):
-    """Concatenate shard results in rank order (shards are contiguous segment ranges, so this IS the
-    canonical (segment, encoding, rank) order); pool offsets are rebased."""
-    recs, pool, base = [], [], 0
-    for r in parts:
-        arr = (Triplex * r.count).from_buffer_copy(r.recs) if r.count else []
-        for t in arr:
-            t.tfo_off += base
-            t.tts_off += base
-        recs.append(bytes(arr) if r.count else b"")
-        pool.append(r.pool)
-        base += len(r.pool)
-    return ScanResult(b"".join(recs), b"".join(pool), {})
+    """Concatenate shard results in rank order (shards are contiguous segment ranges, so this IS the canonical
+    (segment, encoding, rank) order); pool offsets are rebased.  Native: fasim_merge_results, one pass per shard."""
+    parts = list(parts)
+    return _merge_pointers([r.pointers() for r in parts])      # `parts` keeps the source buffers alive during the call
 
 
 def shard_segments(nseg: int, rank: int, world: int):
@@ -184,28 +251,69 @@ def shard_segments(nseg: int, rank: int, world: int):
 def gather_results(res: ScanResult, dist, rank: int, world: int, device: str = "cuda"):
     """The path's only exchange step: every rank contributes the records of its segment shard, rank 0 gets them
     merged in rank order (= canonical (segment, encoding, rank) order because shards are contiguous).
-    Two collectives: an all_gather of (records bytes, pool bytes) and a gather of the padded payloads.
-    `dist` is torch.distributed (backend nccl = RCCL over xGMI on the GPU box; gloo in the CPU tests)."""
+    One all_gather of (records bytes, pool bytes), then grouped point-to-point transfers (RCCL send/recv over xGMI;
+    gloo in the CPU tests) that put every shard's records and pool straight at their final positions of one flat
+    buffer on rank 0; the pool offsets are then rebased in place (fasim_rebase_offsets).  No per-record work in
+    Python and no second copy of the merged records."""
     import torch
     if world == 1:
         return res
-    sizes = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(sizes, torch.tensor([len(res.recs), len(res.pool)], dtype=torch.int64, device=device))
-    mx = max(1, max(int(s.sum()) for s in sizes))
-    buf = torch.zeros(mx, dtype=torch.uint8, device=device)
-    payload = res.recs + res.pool
-    if payload:
-        buf[: len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(device)
-    gathered = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
-    dist.gather(buf, gathered, dst=0)
+    L = lib()
+    rp, cnt, pp, plen = res.pointers()
+    rsz = C.sizeof(Triplex)
+    nr = cnt * rsz
+    gathered = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(gathered, torch.tensor([nr, plen], dtype=torch.int64, device=device))
+    sizes = [(int(s[0]), int(s[1])) for s in gathered]
+    pin = device != "cpu"
+    stage = torch.empty(max(1, nr + plen), dtype=torch.uint8, pin_memory=pin)
+    if nr:
+        C.memmove(stage.data_ptr(), rp, nr)
+    if plen:
+        C.memmove(stage.data_ptr() + nr, pp, plen)
+    mine = stage.to(device, non_blocking=True) if pin else stage
     if rank != 0:
+        ops = []
+        if nr:
+            ops.append(dist.P2POp(dist.isend, mine[:nr], 0))
+        if plen:
+            ops.append(dist.P2POp(dist.isend, mine[nr:nr + plen], 0))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
         return None
-    parts = []
-    for s, g in zip(sizes, gathered):
-        nr, npool = int(s[0]), int(s[1])
-        b = g[: nr + npool].cpu().numpy().tobytes()
-        parts.append(ScanResult(b[:nr], b[nr:], {}))
-    return merge_results(parts)
+    tot_r = sum(a for a, _ in sizes)
+    tot_p = sum(b for _, b in sizes)
+    flat = torch.empty(max(1, tot_r + tot_p), dtype=torch.uint8, device=device)     # [records of all shards][pools of all shards]
+    ops, roff, poff, layout = [], 0, 0, []
+    for k, (a, b) in enumerate(sizes):
+        layout.append((roff, a // rsz, poff))
+        if k == 0:
+            if a:
+                flat[roff:roff + a].copy_(mine[:a])
+            if b:
+                flat[tot_r + poff:tot_r + poff + b].copy_(mine[a:a + b])
+        else:
+            if a:
+                ops.append(dist.P2POp(dist.irecv, flat[roff:roff + a], k))
+            if b:
+                ops.append(dist.P2POp(dist.irecv, flat[tot_r + poff:tot_r + poff + b], k))
+        roff += a
+        poff += b
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    if pin:
+        host = torch.empty(flat.shape, dtype=torch.uint8, pin_memory=True)
+        host.copy_(flat, non_blocking=True)
+        torch.cuda.synchronize()
+    else:
+        host = flat
+    base = host.data_ptr()
+    for roff, n, poff in layout:
+        if n and poff:
+            L.fasim_rebase_offsets(base + roff, n, poff)
+    return ScanResult(stats={}, _ext=(base, tot_r // rsz, base + tot_r, tot_p, host))
 
 
 class Engine:
@@ -296,22 +404,33 @@ class Engine:
         """Upload one DNA record and keep it resident in HBM; scan(None, ...) then scans it without H2D copies."""
         self._check(self._L.fasim_load_dna(self._h, dna, len(dna)))
 
+    @staticmethod
+    def _stats_dict(st) -> dict:
+        stats = {}
+        for k, _ in ScanStats._fields_:
+            v = getattr(st, k)
+            stats[k] = list(v) if hasattr(v, "__len__") else v
+        return stats
+
     def scan(self, dna: bytes | None, params: Params | None = None, seg_first: int = 0, seg_count: int = -1) -> ScanResult:
         p = params or default_params()
         res = C.POINTER(_Result)()
         self._check(self._L.fasim_scan(self._h, dna, len(dna) if dna is not None else 0, seg_first, seg_count, C.byref(p),
                                        C.byref(res)))
-        try:
-            r = res.contents
-            recs = C.string_at(r.recs, r.count * C.sizeof(Triplex)) if r.count else b""
-            pool = C.string_at(r.pool, r.pool_len) if r.pool_len else b""
-            stats = {}
-            for k, _ in ScanStats._fields_:
-                v = getattr(r.stats, k)
-                stats[k] = list(v) if hasattr(v, "__len__") else v
-        finally:
-            self._L.fasim_result_free(res)
-        return ScanResult(recs, pool, stats)
+        return ScanResult(stats=self._stats_dict(res.contents.stats), _native=res)
+
+    def scan_queries(self, rnas, dna: bytes | None, params: Params | None = None, seg_first: int = 0, seg_count: int = -1):
+        """Multi-lncRNA batch (fasim_scan_queries): one ScanResult per lncRNA, each identical to what scan() returns for
+        that lncRNA alone; the DNA record stays resident and the lncRNAs share one work queue."""
+        p = params or default_params()
+        n = len(rnas)
+        arr = (C.c_char_p * n)(*rnas)
+        lens = (C.c_int32 * n)(*[len(r) for r in rnas])
+        outs = (C.POINTER(_Result) * n)()
+        self._check(self._L.fasim_scan_queries(self._h, arr, lens, n, dna, len(dna) if dna is not None else 0, seg_first,
+                                               seg_count, C.byref(p), outs))
+        self.m = len(rnas[-1])
+        return [ScanResult(stats=self._stats_dict(outs[k].contents.stats), _native=outs[k]) for k in range(n)]
 
 
 def pick_candidates(cols, threshold):
@@ -342,15 +461,18 @@ def segment_count(dna_len: int, params: Params | None = None) -> int:
     return lib().fasim_segment_count(dna_len, C.byref(p))
 
 
-def tfosorted(result: ScanResult, chr_name: str, start_genome: int, params: Params | None = None) -> bytes:
+TAIL_CLAMP_CLUSTER = 1
+
+
+def tfosorted(result: ScanResult, chr_name: str, start_genome: int, params: Params | None = None, flags: int = 0) -> bytes:
     """-TFOsorted bytes for the (merged) records; host-side tail of the path."""
     L = lib()
     p = params or default_params()
     text = C.c_void_p()
     n = C.c_int64()
-    recs = C.create_string_buffer(result.recs, len(result.recs)) if result.recs else None
-    rc = L.fasim_tfosorted(C.cast(recs, C.c_void_p) if recs is not None else None, result.count, result.pool or b"\0",
-                           max(1, len(result.pool)), chr_name.encode(), start_genome, C.byref(p), C.byref(text), C.byref(n))
+    rp, cnt, pp, plen = result.pointers()
+    rc = L.fasim_tfosorted_ex(rp or None, cnt, pp or C.addressof(_EMPTY_POOL), max(1, plen), chr_name.encode(),
+                              start_genome, C.byref(p), flags, C.byref(text), C.byref(n))
     if rc != 0:
         raise FasimError(f"fasim_tfosorted failed ({rc}): {L.fasim_last_error(None).decode()}")
     try:
@@ -360,15 +482,15 @@ def tfosorted(result: ScanResult, chr_name: str, start_genome: int, params: Para
 
 
 def tfoclass(result: ScanResult, level: int, chr_name: str, start_genome: int, dna_len: int, rna_name: str,
-             params: Params | None = None) -> bytes:
+             params: Params | None = None, flags: int = 0) -> bytes:
     """-TFOclass<level>-<ds>-<lg> bedGraph bytes (print_cluster, Fasim-LongTarget.cpp:694) for the merged records."""
     L = lib()
     p = params or default_params()
     text = C.c_void_p()
     n = C.c_int64()
-    recs = C.create_string_buffer(result.recs, len(result.recs)) if result.recs else None
-    rc = L.fasim_tfoclass(C.cast(recs, C.c_void_p) if recs is not None else None, result.count, level, chr_name.encode(),
-                          start_genome, dna_len, rna_name.encode(), C.byref(p), C.byref(text), C.byref(n))
+    rp, cnt, _, _ = result.pointers()
+    rc = L.fasim_tfoclass_ex(rp or None, cnt, level, chr_name.encode(), start_genome, dna_len, rna_name.encode(), C.byref(p),
+                             flags, C.byref(text), C.byref(n))
     if rc != 0:
         raise FasimError(f"fasim_tfoclass failed ({rc}): {L.fasim_last_error(None).decode()}")
     try:

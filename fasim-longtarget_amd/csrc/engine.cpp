@@ -92,6 +92,8 @@ struct fasim_engine {
 	// resident DNA record (fasim_load_dna)
 	std::string dna_host;
 	DevBuf dna_res;
+	// streaming ingest (fasim_scan with a host buffer): pinned staging buffer of this worker's current batch slice
+	void* pin_dna = nullptr; size_t pin_cap = 0;
 	// HIP-event timing of kernel launches on `st`
 	struct Timed { hipEvent_t a, b; int family; };
 	std::vector<Timed> timed;
@@ -319,7 +321,7 @@ int run_scan_v2(fasim_engine* E, const UnitBatch& B, const std::vector<char>& un
 			B.tstride, E->stage1_in.as<int32_t>(), E->st);
 		if (he != hipSuccess) return fail(E, FASIM_E_HIP, "max16 launch failed: %s", hipGetErrorString(he));
 		HIPOK(hipStreamSynchronize(E->st));
-		if (st) st->stage1_word_reruns += (int64_t)sep.size();
+		if (st) { st->stage1_word_reruns += (int64_t)sep.size(); for (int u : sep) st->cells_stage1 += (int64_t)E->m * B.unit_len[u]; }
 	}
 	rc = upload(E, E->unit_ids, ids.data(), sizeof(int32_t) * nu); if (rc) return rc;
 	L.unit_ids = E->unit_ids.as<int32_t>(); L.nwork = nu; L.qcodes = E->q2.as<uint8_t>(); fill_scores(L.score, false);
@@ -555,13 +557,13 @@ int run_align(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>
 		const int k = bidx[i];
 		const AlignEnds& e = ends[k];
 		AlignResult& r = out[k];
-		if (bo[i].status != 0) { r.sw_score = 0; continue; }    // NULL from ssw_align -> sw_score 0 (ssw_cpp.cpp:631-633)
+		if (bo[i].status != 0) { r.sw_score = 0; r.failed = 1; continue; }    // NULL from ssw_align -> sw_score 0 (ssw_cpp.cpp:631-633)
 		r.sw_score = bp[i].score; r.ref_begin = e.ref_begin; r.ref_end = e.ref_end;
 		r.query_begin = e.read_begin; r.query_end = e.read_end;
 		if (via_finish[i]) {
 			r.cigar_len = fres[i].cigar_len; r.cigar_off = fres[i].cigar_off;
 			if (from_sys[k]) { r.ref_begin = fres[i].ref_begin; r.query_begin = fres[i].query_begin; }
-			if (fres[i].sw_score <= 0) r.sw_score = 0;
+			if (fres[i].sw_score <= 0) { r.sw_score = 0; r.failed = 1; }
 			continue;
 		}
 		r.cigar_len = bo[i].cigar_len;
@@ -791,7 +793,7 @@ int run_align_v2(fasim_engine* E, const UnitBatch& B, const std::vector<WindowPr
 	std::vector<char> status;
 	rc = run_finish(E, B, W, fo, out, cigars, status); if (rc) return rc;
 	std::vector<int> redo;
-	for (int k = 0; k < n; k++) { if (status[k] == 2) redo.push_back(k); else if (status[k] == 1) out[k].sw_score = 0; }
+	for (int k = 0; k < n; k++) { if (status[k] == 2) redo.push_back(k); else if (status[k] == 1) { out[k].sw_score = 0; out[k].failed = 1; } }
 	if (!redo.empty()) {
 		std::vector<WindowProb> W2(redo.size());
 		for (size_t i = 0; i < redo.size(); i++) W2[i] = W[redo[i]];
@@ -899,6 +901,7 @@ void fasim_engine_destroy(fasim_engine* e)
 	for (auto& t : e->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
 	for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
 	for (DevBuf* b : bufs) b->release();
+	if (e->pin_dna) (void)hipHostFree(e->pin_dna);
 	if (e->st_heavy && e->st_heavy != e->st) (void)hipStreamDestroy(e->st_heavy);
 	if (e->st) (void)hipStreamDestroy(e->st);
 	delete e;
@@ -973,6 +976,32 @@ int fasim_ssw_pre_align(fasim_engine* E, const char* target, int32_t n, int32_t*
 	return fasim_pre_align_batch(E, target, &off, &n, 1, out_cols, nullptr);
 }
 
+int fasim_ssw_colmax_word(fasim_engine* E, const char* target, int32_t n, int32_t* out_cols)
+{
+	int rc = need_query(E); if (rc) return rc;
+	if (!target || !out_cols || n <= 0) return fail(E, FASIM_E_ARG, "bad arguments");
+	HIPOK(hipSetDevice(E->device));
+	UnitBatch B;
+	const int64_t off = 0;
+	rc = load_raw_targets(E, target, &off, &n, 1, false, B); if (rc) return rc;
+	HIPOK(E->colmax16.ensure((size_t)B.tstride * sizeof(uint16_t)));
+	HIPOK(E->max_out.ensure(sizeof(int32_t)));
+	const std::vector<StripedProb> probs = whole_unit_probs(B, E->m, nullptr);
+	rc = upload(E, E->probs, probs.data(), probs.size() * sizeof(StripedProb)); if (rc) return rc;
+	StripedLaunch L;
+	L.tcodes = E->tcodes.as<uint8_t>(); L.qcodes = E->q2.as<uint8_t>(); L.probs = E->probs.as<StripedProb>(); L.nprob = 1;
+	L.counter = E->counter.as<uint32_t>(); L.lut = E->lut2; L.max_qlen = E->m; L.colmax = nullptr;
+	L.colmax_w = E->colmax16.as<uint16_t>(); L.max_out = E->max_out.as<int32_t>(); L.ends = nullptr;
+	const hipError_t he = launch_striped(MODE_PRE, true, false, L, E->st);
+	if (he == hipErrorInvalidValue) return fail(E, FASIM_E_UNSUPPORTED, "query of %d nt does not fit the LDS-resident striped kernel", E->m);
+	if (he != hipSuccess) return fail(E, FASIM_E_HIP, "striped kernel launch failed: %s", hipGetErrorString(he));
+	std::vector<uint16_t> cm((size_t)n);
+	HIPOK(hipMemcpyAsync(cm.data(), E->colmax16.p, sizeof(uint16_t) * (size_t)n, hipMemcpyDeviceToHost, E->st));
+	HIPOK(hipStreamSynchronize(E->st));
+	for (int c = 0; c < n; c++) out_cols[c] = cm[(size_t)c];
+	return FASIM_OK;
+}
+
 int fasim_pick_candidates(const int32_t* cols, int32_t n, int32_t threshold, int32_t* out_score, int32_t* out_pos,
 	int32_t cap, int32_t* count)
 {
@@ -1004,6 +1033,7 @@ int fasim_align_batch(fasim_engine* E, const char* windows, const int64_t* offse
 		out[i].query_begin = res[i].query_begin; out[i].query_end = res[i].query_end;
 		out[i].cigar_len = std::min(res[i].cigar_len, 256);
 		if (out[i].cigar_len) memcpy(out[i].cigar, cigars.data() + res[i].cigar_off, sizeof(uint32_t) * out[i].cigar_len);
+		if (res[i].failed) { out[i].sw_score = 0; out[i].cigar_len = -1; }     // the reference returns NULL here
 	}
 	return FASIM_OK;
 }
@@ -1079,6 +1109,22 @@ int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t*
 	{
 		// segments of this batch that are not skipped by same_seq()
 		std::vector<int32_t> sstart, slen; std::vector<int64_t> sidx;
+		if (!dna_dev) {
+			// Streaming ingest: the record is in host memory only.  The slice this batch needs goes through the worker's
+			// pinned staging buffer and its own stream; with ~10 batches in flight the copy of one batch overlaps the kernels
+			// of the others, and HBM holds 10 slices of ~2.5 MB instead of the whole record.
+			const int64_t lo = b0 * step, hi = std::min<int64_t>(dna_len, (b1 - 1) * step + p.cutLength);
+			const size_t bytes = (size_t)(hi - lo);
+			if (bytes > E->pin_cap) {
+				if (E->pin_dna) { (void)hipHostFree(E->pin_dna); E->pin_dna = nullptr; E->pin_cap = 0; }
+				HIPOK(hipHostMalloc(&E->pin_dna, bytes + bytes / 8, hipHostMallocDefault));
+				E->pin_cap = bytes + bytes / 8;
+			}
+			memcpy(E->pin_dna, dna + lo, bytes);
+			HIPOK(E->dna.ensure(bytes));
+			HIPOK(hipMemcpyAsync(E->dna.p, E->pin_dna, bytes, hipMemcpyHostToDevice, E->st));
+			dna_dev = E->dna.as<uint8_t>(); shard_lo = lo;
+		}
 		for (int64_t s = b0; s < b1; s++) {
 			const int64_t pos = s * step;
 			const int len = (int)std::min<int64_t>(p.cutLength, dna_len - pos);
@@ -1092,7 +1138,9 @@ int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t*
 		UnitBatch B; B.nunit = nseg * nenc; B.tstride = tstride; B.unit_len.resize(B.nunit);
 		for (int s = 0; s < nseg; s++) for (int k = 0; k < nenc; k++) B.unit_len[s * nenc + k] = slen[s];
 		st.units += B.nunit;
-		for (int s = 0; s < nseg; s++) { st.cells_stage1 += (int64_t)E->m * slen[s] * nenc; st.cells_stage2 += (int64_t)E->m * slen[s] * nenc; }
+		// executed DP cells: the fused k_scan pass serves stage 1 AND stage 2, so it is counted once (as stage 2); stage 1 is
+		// counted only where it really is a pass of its own (units with N / non-ACGT queries, the striped fallback)
+		for (int s = 0; s < nseg; s++) st.cells_stage2 += (int64_t)E->m * slen[s] * nenc;
 		rc = upload(E, E->seg_start, sstart.data(), sizeof(int32_t) * nseg); if (rc) return rc;
 		rc = upload(E, E->seg_len, slen.data(), sizeof(int32_t) * nseg); if (rc) return rc;
 		rc = upload(E, E->unit_len, B.unit_len.data(), sizeof(int32_t) * B.nunit); if (rc) return rc;
@@ -1128,6 +1176,7 @@ int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t*
 		// ---- stage 1
 		t0 = now_s();
 		std::vector<int> s1;
+		for (int u = 0; u < B.nunit; u++) st.cells_stage1 += (int64_t)E->m * B.unit_len[u];
 		rc = run_stage1(E, B, s1, &st.stage1_word_reruns); if (rc) return rc;
 		st.t_stage1_s += now_s() - t0;
 
@@ -1382,23 +1431,70 @@ int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t*
 	return FASIM_OK;
 }
 
-int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_first, int64_t seg_count,
-	const fasim_params* pp, fasim_result** out)
+// pack the records of one query into the C result
+static int pack_result(fasim_engine* E, std::vector<HostTriplex>& all, const fasim_scan_stats& st, fasim_result** out)
 {
-	int rc = need_query(E); if (rc) return rc;
+	fasim_result* R = (fasim_result*)calloc(1, sizeof(fasim_result));
+	if (!R) return fail(E, FASIM_E_NOMEM, "out of memory");
+	size_t pool = 0;
+	for (const HostTriplex& t : all) pool += t.tfo.size() + t.tts.size() + 2;
+	R->count = (int64_t)all.size();
+	R->recs = (fasim_triplex*)calloc(std::max<size_t>(1, all.size()), sizeof(fasim_triplex));
+	R->pool = (char*)calloc(std::max<size_t>(1, pool), 1);
+	if (!R->recs || !R->pool) { fasim_result_free(R); return fail(E, FASIM_E_NOMEM, "out of memory"); }
+	R->pool_len = (int64_t)pool;
+	size_t off = 0;
+	for (size_t i = 0; i < all.size(); i++) {
+		const HostTriplex& t = all[i];
+		fasim_triplex& r = R->recs[i];
+		r.stari = t.stari; r.endi = t.endi; r.starj = t.starj; r.endj = t.endj; r.strand = t.strand; r.reverse = t.reverse;
+		r.rule = t.rule; r.nt = t.nt; r.score = t.score; r.identity = t.identity; r.tri_score = t.tri_score; r.seg = t.seg; r.enc = t.enc;
+		r.tfo_off = (int64_t)off; memcpy(R->pool + off, t.tfo.c_str(), t.tfo.size() + 1); off += t.tfo.size() + 1;
+		r.tts_off = (int64_t)off; memcpy(R->pool + off, t.tts.c_str(), t.tts.size() + 1); off += t.tts.size() + 1;
+	}
+	R->stats = st;
+	*out = R;
+	return FASIM_OK;
+}
+
+static void add_stats(fasim_scan_stats& st, const fasim_scan_stats& x)
+{
+	st.segments += x.segments; st.segments_skipped += x.segments_skipped; st.units += x.units; st.candidates += x.candidates;
+	st.align_calls += x.align_calls; st.align_word_reruns += x.align_word_reruns; st.stage2_overflow_units += x.stage2_overflow_units;
+	st.stage1_word_reruns += x.stage1_word_reruns; st.logical_cells += x.logical_cells; st.t_stage1_s += x.t_stage1_s;
+	st.t_stage2_s += x.t_stage2_s; st.t_stage3_s += x.t_stage3_s; st.t_host_s += x.t_host_s; st.cells_stage1 += x.cells_stage1;
+	st.cells_stage2 += x.cells_stage2; st.cells_stage3 += x.cells_stage3; st.hazard_units += x.hazard_units; st.rev_exact += x.rev_exact;
+	st.exact_replays += x.exact_replays; st.tries_skipped += x.tries_skipped;
+	for (int k = 0; k < 8; k++) { st.kernel_ms[k] += x.kernel_ms[k]; st.kernel_launches[k] += x.kernel_launches[k]; }
+}
+
+// The body of fasim_scan / fasim_scan_queries: every (query, batch of segments) pair is one work item; the worker engines
+// take items from one queue, so the tail of one query's scan overlaps the head of the next (no ramp-up / drain per query).
+// nq == 0: the engine's current query.
+static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rna_lens, int nq, const char* dna, int64_t dna_len,
+	int64_t seg_first, int64_t seg_count, const fasim_params* pp, fasim_result** outs)
+{
 	const bool resident = (dna == nullptr);
 	if (resident) {
 		if (E->dna_host.empty()) return fail(E, FASIM_E_ARG, "no resident DNA: call fasim_load_dna first");
 		dna = E->dna_host.data(); dna_len = (int64_t)E->dna_host.size();
 	}
-	if (!dna || dna_len <= 0 || !pp || !out) return fail(E, FASIM_E_ARG, "bad arguments");
+	if (!dna || dna_len <= 0 || !pp || !outs) return fail(E, FASIM_E_ARG, "bad arguments");
 	const fasim_params p = *pp;
 	if (p.cutLength <= 0 || p.cutLength - p.overlapLength <= 0) return fail(E, FASIM_E_ARG, "cutLength/overlapLength invalid");
 	if (dna_len > 0x7fffffffll) return fail(E, FASIM_E_ARG, "one record is limited to 2^31-1 nt (the reference's int positions)");
 	HIPOK(hipSetDevice(E->device));
 	const double t_begin = now_s();
-	fasim_scan_stats st; memset(&st, 0, sizeof st);
 	{ const char* pe = getenv("FASIM_PROFILE"); g_prof.on = pe && atoi(pe) != 0; g_prof.reset(); }
+
+	std::vector<std::string> queries;
+	if (nq <= 0) queries.push_back(E->rna);
+	else for (int q = 0; q < nq; q++) {
+		if (!rnas || !rna_lens || !rnas[q] || rna_lens[q] <= 0) return fail(E, FASIM_E_ARG, "empty query %d", q);
+		queries.emplace_back(rnas[q], rnas[q] + rna_lens[q]);
+	}
+	const int nquery = (int)queries.size();
+	for (int q = 0; q < nquery; q++) outs[q] = nullptr;
 
 	const int64_t nseg_all = fasim_segment_count(dna_len, &p);
 	if (seg_first < 0) seg_first = 0;
@@ -1407,14 +1503,16 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 	const std::vector<int> encs = enabled_encodings(p);
 	const int nenc = (int)encs.size();
 
-	std::vector<HostTriplex> all;
+	std::vector<std::vector<HostTriplex>> all(nquery);
+	std::vector<fasim_scan_stats> qst(nquery);
+	for (auto& x : qst) memset(&x, 0, sizeof x);
 	if (seg_count > 0 && nenc > 0) {
-		// the shard's DNA stays resident for the whole scan
+		// the shard's DNA stays resident for the whole scan (all queries)
 		const int64_t shard_lo = seg_first * step;
 		const int64_t shard_hi = std::min<int64_t>(dna_len, (seg_first + seg_count - 1) * step + p.cutLength);
-		const uint8_t* dna_dev;
-		if (resident) dna_dev = E->dna_res.as<uint8_t>() + shard_lo;
-		else { rc = upload(E, E->dna, dna + shard_lo, (size_t)(shard_hi - shard_lo)); if (rc) return rc; dna_dev = E->dna.as<uint8_t>(); }
+		// resident record: the kernels read it in place; host buffer: every batch streams its own slice (scan_batch)
+		const uint8_t* dna_dev = resident ? E->dna_res.as<uint8_t>() + shard_lo : nullptr;
+		(void)shard_hi;
 		const int tstride = (p.cutLength + 15) & ~15;
 		// Batches of ~512 segments x 48 encodings; several batches are in flight at once on worker engines (own HIP
 		// stream + buffers + host thread), so the latency-bound kernels (stripe-faithful re-runs, tracebacks) and the
@@ -1445,11 +1543,15 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 				b0 += len;
 			}
 		}
-		nworkers = (int)std::min<size_t>((size_t)nworkers, chunks.size());
-		// worker 0 is this engine; the others are lazily created engines on the same device sharing the query
+		struct Item { int q; int64_t b0, b1; };
+		std::vector<Item> items;
+		items.reserve(chunks.size() * (size_t)nquery);
+		for (int q = 0; q < nquery; q++) for (const auto& c : chunks) items.push_back({ q, c.first, c.second });
+		nworkers = (int)std::min<size_t>((size_t)nworkers, items.size());
+		// worker 0 is this engine; the others are lazily created engines on the same device
 		while ((int)E->workers.size() < nworkers - 1) {
 			fasim_engine* w = nullptr;
-			rc = fasim_engine_create(E->device, &w); if (rc) return fail(E, rc, "cannot create worker engine: %s", fasim_last_error(nullptr));
+			int rc = fasim_engine_create(E->device, &w); if (rc) return fail(E, rc, "cannot create worker engine: %s", fasim_last_error(nullptr));
 			E->workers.push_back(w);
 		}
 		std::vector<fasim_engine*> ws(1, E);
@@ -1460,28 +1562,40 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 		}
 		for (fasim_engine* w : ws) {
 			w->gate = (ws.size() > 1 && E->own_gate.cap > 0) ? &E->own_gate : nullptr;
-			if (w != E && (w->rna != E->rna)) { rc = fasim_set_query(w, E->rna.data(), E->m); if (rc) return fail(E, rc, "worker set_query failed: %s", fasim_last_error(w)); }
 			w->scan_v1 = E->scan_v1; w->align_v1 = E->align_v1;
 			w->host_threads = std::max(1, E->host_threads_total / nworkers);
 			HIPOK(hipSetDevice(E->device));
-			rc = upload(w, w->enc_ids, encs.data(), sizeof(int) * nenc); if (rc) return rc;
+			int rc = upload(w, w->enc_ids, encs.data(), sizeof(int) * nenc); if (rc) return rc;
 			drain_timed(w);
 			for (int k = 0; k < 8; k++) { w->kernel_ms[k] = 0; w->kernel_launches[k] = 0; }
 		}
-		std::vector<std::vector<HostTriplex>> per_chunk(chunks.size());
-		std::vector<fasim_scan_stats> wst(ws.size());
-		for (auto& x : wst) memset(&x, 0, sizeof x);
+		std::vector<std::vector<HostTriplex>> per_item(items.size());
+		std::vector<fasim_scan_stats> ist(items.size());
+		for (auto& x : ist) memset(&x, 0, sizeof x);
+		std::vector<double> it0(items.size(), 0.0), it1(items.size(), 0.0);
 		std::vector<int> wrc(ws.size(), FASIM_OK);
 		std::atomic<size_t> next(0);
 		auto run = [&](size_t wi) {
 			(void)hipSetDevice(E->device);
+			fasim_engine* w = ws[wi];
 			for (;;) {
 				const size_t c = next.fetch_add(1);
-				if (c >= chunks.size()) break;
-				const int r = scan_batch(ws[wi], dna, dna_len, dna_dev, shard_lo, chunks[c].first, chunks[c].second, p, encs, tstride, per_chunk[c], wst[wi]);
+				if (c >= items.size()) break;
+				const Item& itx = items[c];
+				const std::string& rq = queries[(size_t)itx.q];
+				it0[c] = now_s();
+				if (w->rna != rq) {          // the worker switches to this item's lncRNA (2 x m bytes H2D)
+					const int r = fasim_set_query(w, rq.data(), (int)rq.size());
+					if (r) { if (w != E) w->err = std::string("worker set_query failed: ") + w->err; wrc[wi] = r; break; }
+				}
+				const int r = scan_batch(w, dna, dna_len, dna_dev, shard_lo, itx.b0, itx.b1, p, encs, tstride, per_item[c], ist[c]);
 				if (r) { wrc[wi] = r; break; }
+				(void)hipStreamSynchronize(w->st);
+				drain_timed(w);
+				for (int k = 0; k < 8; k++) { ist[c].kernel_ms[k] = w->kernel_ms[k]; ist[c].kernel_launches[k] = w->kernel_launches[k]; w->kernel_ms[k] = 0; w->kernel_launches[k] = 0; }
+				it1[c] = now_s();
 			}
-			(void)hipStreamSynchronize(ws[wi]->st);
+			(void)hipStreamSynchronize(w->st);
 		};
 		if (g_prof.on) fprintf(stderr, "[fasim prof] scan head (setup before the workers start)  %.3f s\n", now_s() - t_begin);
 		const double t_workers = now_s();
@@ -1489,50 +1603,95 @@ int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_fi
 		else { std::vector<std::thread> th; for (size_t wi = 0; wi < ws.size(); wi++) th.emplace_back(run, wi); for (auto& t : th) t.join(); }
 		if (g_prof.on) fprintf(stderr, "[fasim prof] scan workers                                  %.3f s\n", now_s() - t_workers);
 		for (size_t wi = 0; wi < ws.size(); wi++) if (wrc[wi]) { if (ws[wi] != E) E->err = ws[wi]->err; return wrc[wi]; }
-		for (auto& v : per_chunk) for (HostTriplex& t : v) all.push_back(std::move(t));
-		for (size_t wi = 0; wi < ws.size(); wi++) {
-			const fasim_scan_stats& x = wst[wi];
-			st.segments += x.segments; st.segments_skipped += x.segments_skipped; st.units += x.units; st.candidates += x.candidates;
-			st.align_calls += x.align_calls; st.align_word_reruns += x.align_word_reruns; st.stage2_overflow_units += x.stage2_overflow_units;
-			st.stage1_word_reruns += x.stage1_word_reruns; st.logical_cells += x.logical_cells; st.t_stage1_s += x.t_stage1_s;
-			st.t_stage2_s += x.t_stage2_s; st.t_stage3_s += x.t_stage3_s; st.t_host_s += x.t_host_s; st.cells_stage1 += x.cells_stage1;
-			st.cells_stage2 += x.cells_stage2; st.cells_stage3 += x.cells_stage3; st.hazard_units += x.hazard_units; st.rev_exact += x.rev_exact; st.exact_replays += x.exact_replays; st.tries_skipped += x.tries_skipped;
-			drain_timed(ws[wi]);
-			for (int k = 0; k < 8; k++) { st.kernel_ms[k] += ws[wi]->kernel_ms[k]; st.kernel_launches[k] += ws[wi]->kernel_launches[k]; }
+		// a multi-query call leaves the engine on its LAST query (documented in fasim_hip.h)
+		if (nq > 0 && E->rna != queries.back()) { int rc = fasim_set_query(E, queries.back().data(), (int)queries.back().size()); if (rc) return rc; }
+		std::vector<double> q0(nquery, 1e300), q1(nquery, 0.0);
+		for (size_t c = 0; c < items.size(); c++) {
+			const int q = items[c].q;
+			for (HostTriplex& t : per_item[c]) all[(size_t)q].push_back(std::move(t));
+			add_stats(qst[(size_t)q], ist[c]);
+			q0[q] = std::min(q0[q], it0[c]); q1[q] = std::max(q1[q], it1[c]);
 		}
+		// per query: wall clock from the start of its first batch to the end of its last one (neighbouring queries overlap)
+		for (int q = 0; q < nquery; q++) qst[(size_t)q].t_total_s = nquery == 1 ? 0.0 : std::max(0.0, q1[q] - q0[q]);
 	}
 
-	// pack the records
-	fasim_result* R = (fasim_result*)calloc(1, sizeof(fasim_result));
-	if (!R) return fail(E, FASIM_E_NOMEM, "out of memory");
-	size_t pool = 0;
-	for (const HostTriplex& t : all) pool += t.tfo.size() + t.tts.size() + 2;
-	R->count = (int64_t)all.size();
-	R->recs = (fasim_triplex*)calloc(std::max<size_t>(1, all.size()), sizeof(fasim_triplex));
-	R->pool = (char*)calloc(std::max<size_t>(1, pool), 1);
-	if (!R->recs || !R->pool) { fasim_result_free(R); return fail(E, FASIM_E_NOMEM, "out of memory"); }
-	R->pool_len = (int64_t)pool;
-	size_t off = 0;
-	for (size_t i = 0; i < all.size(); i++) {
-		const HostTriplex& t = all[i];
-		fasim_triplex& r = R->recs[i];
-		r.stari = t.stari; r.endi = t.endi; r.starj = t.starj; r.endj = t.endj; r.strand = t.strand; r.reverse = t.reverse;
-		r.rule = t.rule; r.nt = t.nt; r.score = t.score; r.identity = t.identity; r.tri_score = t.tri_score; r.seg = t.seg; r.enc = t.enc;
-		r.tfo_off = (int64_t)off; memcpy(R->pool + off, t.tfo.c_str(), t.tfo.size() + 1); off += t.tfo.size() + 1;
-		r.tts_off = (int64_t)off; memcpy(R->pool + off, t.tts.c_str(), t.tts.size() + 1); off += t.tts.size() + 1;
+	if (nquery == 1) qst[0].t_total_s = now_s() - t_begin;
+	for (int q = 0; q < nquery; q++) {
+		const int rc = pack_result(E, all[(size_t)q], qst[(size_t)q], &outs[q]);
+		if (rc) { for (int k = 0; k < q; k++) { fasim_result_free(outs[k]); outs[k] = nullptr; } return rc; }
 	}
-	st.t_total_s = now_s() - t_begin;
+	if (nquery == 1) outs[0]->stats.t_total_s = now_s() - t_begin;
 	if (g_prof.on) {
-		fprintf(stderr, "[fasim prof] total %.3f s  stage2 %.3f  stage3 %.3f  host %.3f\n", st.t_total_s, st.t_stage2_s, st.t_stage3_s, st.t_host_s);
+		double tot = now_s() - t_begin;
+		fprintf(stderr, "[fasim prof] total %.3f s  stage2 %.3f  stage3 %.3f  host %.3f\n", tot, qst[0].t_stage2_s, qst[0].t_stage3_s, qst[0].t_host_s);
 		g_prof.dump();
 	}
-	R->stats = st;
+	return FASIM_OK;
+}
+
+int fasim_scan(fasim_engine* E, const char* dna, int64_t dna_len, int64_t seg_first, int64_t seg_count,
+	const fasim_params* pp, fasim_result** out)
+{
+	int rc = need_query(E); if (rc) return rc;
+	if (!out) return fail(E, FASIM_E_ARG, "bad arguments");
+	return scan_core(E, nullptr, nullptr, 0, dna, dna_len, seg_first, seg_count, pp, out);
+}
+
+int fasim_scan_queries(fasim_engine* E, const char* const* rnas, const int32_t* rna_lens, int32_t nq, const char* dna,
+	int64_t dna_len, int64_t seg_first, int64_t seg_count, const fasim_params* pp, fasim_result** outs)
+{
+	if (!E) return fail(nullptr, FASIM_E_ARG, "null engine");
+	if (nq <= 0 || !rnas || !rna_lens || !outs) return fail(E, FASIM_E_ARG, "bad arguments");
+	return scan_core(E, rnas, rna_lens, nq, dna, dna_len, seg_first, seg_count, pp, outs);
+}
+
+// in-place variant for a gather that already placed every shard's records and pool at their final positions
+int fasim_rebase_offsets(fasim_triplex* recs, int64_t count, int64_t delta)
+{
+	if (count < 0 || (count > 0 && !recs)) return fail(nullptr, FASIM_E_ARG, "bad arguments");
+	for (int64_t i = 0; i < count; i++) { recs[i].tfo_off += delta; recs[i].tts_off += delta; }
+	return FASIM_OK;
+}
+
+// ---- the exchange step's host half: shard results -> one result, in the order given ------------------------------
+int fasim_merge_results(const fasim_triplex* const* recs, const int64_t* counts, const char* const* pools,
+	const int64_t* pool_lens, int32_t nparts, fasim_result** out)
+{
+	if (nparts < 0 || !out || (nparts > 0 && (!recs || !counts || !pools || !pool_lens))) return fail(nullptr, FASIM_E_ARG, "bad arguments");
+	int64_t total = 0, pool_total = 0;
+	std::vector<int64_t> rbase((size_t)nparts), pbase((size_t)nparts);
+	for (int k = 0; k < nparts; k++) {
+		if (counts[k] < 0 || pool_lens[k] < 0 || (counts[k] > 0 && (!recs[k] || !pools[k]))) return fail(nullptr, FASIM_E_ARG, "bad part %d", k);
+		rbase[(size_t)k] = total; pbase[(size_t)k] = pool_total;
+		total += counts[k]; pool_total += pool_lens[k];
+	}
+	fasim_result* R = (fasim_result*)calloc(1, sizeof(fasim_result));
+	if (!R) return fail(nullptr, FASIM_E_NOMEM, "out of memory");
+	R->recs = (fasim_triplex*)malloc(std::max<size_t>(1, (size_t)total) * sizeof(fasim_triplex));
+	R->pool = (char*)malloc(std::max<size_t>(1, (size_t)pool_total));
+	if (!R->recs || !R->pool) { fasim_result_free(R); return fail(nullptr, FASIM_E_NOMEM, "out of memory"); }
+	R->count = total; R->pool_len = pool_total;
+	// one pass per part: copy the records with their pool offsets rebased, copy the pool; parts are independent, so
+	// large merges run one host thread per part
+	auto one = [&](int k) {
+		fasim_triplex* dst = R->recs + rbase[(size_t)k];
+		const fasim_triplex* src = recs[k];
+		const int64_t pb = pbase[(size_t)k];
+		for (int64_t i = 0; i < counts[k]; i++) { fasim_triplex t = src[i]; t.tfo_off += pb; t.tts_off += pb; dst[i] = t; }
+		if (pool_lens[k]) memcpy(R->pool + pb, pools[k], (size_t)pool_lens[k]);
+	};
+	if (nparts > 1 && total + pool_total / 64 > 100000) {
+		std::vector<std::thread> th;
+		for (int k = 0; k < nparts; k++) th.emplace_back(one, k);
+		for (auto& t : th) t.join();
+	} else for (int k = 0; k < nparts; k++) one(k);
 	*out = R;
 	return FASIM_OK;
 }
 
 static int records_to_list(const fasim_triplex* recs, int64_t count, const char* pool, int64_t pool_len, const fasim_params* p,
-	std::vector<HostTriplex>& list)
+	int64_t start_genome, int32_t flags, std::vector<HostTriplex>& list)
 {
 	list.resize((size_t)count);
 	for (int64_t i = 0; i < count; i++) {
@@ -1542,8 +1701,11 @@ static int records_to_list(const fasim_triplex* recs, int64_t count, const char*
 		t.stari = r.stari; t.endi = r.endi; t.starj = r.starj; t.endj = r.endj; t.strand = r.strand; t.reverse = r.reverse;
 		t.rule = r.rule; t.nt = r.nt; t.score = r.score; t.identity = r.identity; t.tri_score = r.tri_score; t.seg = r.seg; t.enc = r.enc;
 		t.tfo = pool ? pool + r.tfo_off : ""; t.tts = pool ? pool + r.tts_off : "";
-		if (t.nt > p->cLength && (t.stari + t.endi) / 2 - p->cDistance < 0)
-			return fail(nullptr, FASIM_E_UNSUPPORTED, "a triplex mid-point lies within -ds of the query start: the reference's clustering does not terminate for this input");
+		// records of a later FASTA record in the reference's accumulating reader carry their own genome start (main(),
+		// Fasim-LongTarget.cpp:141-149 patches each record's triplexes with startGenomeTmp[i])
+		if (r.genome_shift != 0) { t.genomestart = (long)r.starj + (long)start_genome + r.genome_shift - 1; t.genomeend = (long)r.endj + (long)start_genome + r.genome_shift - 1; }
+		if (t.nt > p->cLength && (t.stari + t.endi) / 2 - p->cDistance < 0 && !(flags & FASIM_TAIL_CLAMP_CLUSTER))
+			return fail(nullptr, FASIM_E_UNSUPPORTED, "a triplex mid-point lies within -ds of the query start: the reference's clustering does not terminate for this input (FASIM_TAIL_CLAMP_CLUSTER / fasim --clamp-cluster gives a defined result)");
 	}
 	return FASIM_OK;
 }
@@ -1557,26 +1719,44 @@ static int text_out(const std::string& s, char** text, int64_t* text_len)
 	return FASIM_OK;
 }
 
-int fasim_tfosorted(const fasim_triplex* recs, int64_t count, const char* pool, int64_t pool_len, const char* chr,
-	int64_t start_genome, const fasim_params* p, char** text, int64_t* text_len)
+int fasim_tfosorted_ex(const fasim_triplex* recs, int64_t count, const char* pool, int64_t pool_len, const char* chr,
+	int64_t start_genome, const fasim_params* p, int32_t flags, char** text, int64_t* text_len)
 {
 	if ((count > 0 && (!recs || !pool)) || !chr || !p || !text || !text_len || count < 0) return fail(nullptr, FASIM_E_ARG, "bad arguments");
 	std::vector<HostTriplex> list;
-	const int rc = records_to_list(recs, count, pool, pool_len, p, list);
+	const int rc = records_to_list(recs, count, pool, pool_len, p, start_genome, flags, list);
 	if (rc != FASIM_OK) return rc;
 	return text_out(tfosorted_text(list, chr, (long)start_genome, *p), text, text_len);
+}
+
+int fasim_tfosorted(const fasim_triplex* recs, int64_t count, const char* pool, int64_t pool_len, const char* chr,
+	int64_t start_genome, const fasim_params* p, char** text, int64_t* text_len)
+{
+	return fasim_tfosorted_ex(recs, count, pool, pool_len, chr, start_genome, p, 0, text, text_len);
+}
+
+int fasim_tfoclass_ex(const fasim_triplex* recs, int64_t count, int32_t level, const char* chr, int64_t start_genome,
+	int64_t dna_len, const char* rna_name, const fasim_params* p, int32_t flags, char** text, int64_t* text_len)
+{
+	if ((count > 0 && !recs) || !chr || !rna_name || !p || !text || !text_len || count < 0 || level < 1 || level > 5)
+		return fail(nullptr, FASIM_E_ARG, "bad arguments");
+	std::vector<HostTriplex> list;
+	const int rc = records_to_list(recs, count, nullptr, 0, p, start_genome, flags, list);
+	if (rc != FASIM_OK) return rc;
+	cluster_triplex(p->cDistance, p->cLength, list);
+	return text_out(tfoclass_text(list, level, chr, (long)start_genome, (long)dna_len, rna_name, *p), text, text_len);
 }
 
 int fasim_tfoclass(const fasim_triplex* recs, int64_t count, int32_t level, const char* chr, int64_t start_genome,
 	int64_t dna_len, const char* rna_name, const fasim_params* p, char** text, int64_t* text_len)
 {
-	if ((count > 0 && !recs) || !chr || !rna_name || !p || !text || !text_len || count < 0 || level < 1 || level > 5)
-		return fail(nullptr, FASIM_E_ARG, "bad arguments");
-	std::vector<HostTriplex> list;
-	const int rc = records_to_list(recs, count, nullptr, 0, p, list);
-	if (rc != FASIM_OK) return rc;
-	cluster_triplex(p->cDistance, p->cLength, list);
-	return text_out(tfoclass_text(list, level, chr, (long)start_genome, (long)dna_len, rna_name, *p), text, text_len);
+	return fasim_tfoclass_ex(recs, count, level, chr, start_genome, dna_len, rna_name, p, 0, text, text_len);
+}
+
+void fasim_upper_case(char* seq, int64_t n)
+{
+	if (!seq) return;
+	for (int64_t i = 0; i < n; i++) { const char c = seq[i]; if (c >= 'a' && c <= 'z') seq[i] = (char)(c - 32); }
 }
 
 } // extern "C"

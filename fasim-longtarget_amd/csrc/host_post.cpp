@@ -279,7 +279,8 @@ void cluster_triplex(int dd, int length, std::vector<HostTriplex>& list)
 		t.middle = middle; t.motif = 0;
 		by_mid[middle].push_back((int)k);
 		for (int i = -dd; i <= dd; i++) {
-			const int pos = middle + i;          // caller guarantees middle - dd >= 0 (see fasim_tfosorted)
+			const int pos = middle + i;          // middle - dd >= 0 unless the caller asked for FASIM_TAIL_CLAMP_CLUSTER (see
+			if (pos < 0) continue;               // fasim_tfosorted_ex): positions before the query start then do not exist
 			live[pos] = 1;
 			if (i > 0) near[pos] += dd - i; else if (i < 0) near[pos] += dd + i;
 			if (near[pos] > max_near) { max_near = near[pos]; max_pos = pos; find = 1; }

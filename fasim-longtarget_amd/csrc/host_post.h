@@ -24,6 +24,7 @@ struct AlignResult {            // CIGAR ops live in a pool owned by the caller:
 	int sw_score = 0, ref_begin = 0, ref_end = 0, query_begin = 0, query_end = 0;
 	int cigar_len = 0;
 	uint32_t cigar_off = 0;
+	int failed = 0;             // 1: the reference's ssw_align returns NULL here (banded_sw found no path): sw_score is 0
 };
 
 // window length tried at iteration `it` (0..3) for a candidate (fastsim.h:204-211); returns false when the

@@ -16,6 +16,7 @@ struct StripedLaunch {
 	ScoreLut lut;
 	int32_t max_qlen;           // largest q_len in the batch (sizes the LDS stripes)
 	uint8_t* colmax;            // MODE_PRE: u8 column maxima, same indexing as tcodes
+	uint16_t* colmax_w = nullptr;   // MODE_PRE with word == true: u16 column maxima instead
 	int32_t* max_out;           // MODE_PRE / MODE_MAX1: per problem (slot = prob.unit) score, 255 = byte overflow
 	AlignEnds* ends;            // MODE_ALIGN: per problem (slot = index in probs)
 };

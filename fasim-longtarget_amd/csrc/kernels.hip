@@ -61,6 +61,7 @@ struct StripedArgs {
 	ScoreLut lut;
 	int32_t s4;                 // bytes-of-rows stride of one stripe in LDS (multiple of 4, (s4/4) odd)
 	uint8_t* colmax;
+	uint16_t* colmax_w;         // MODE_PRE in word mode: 16-bit column maxima (same indexing as colmax)
 	int32_t* max_out;
 	AlignEnds* ends;
 };
@@ -293,7 +294,9 @@ __global__ void __launch_bounds__(64) k_striped(StripedArgs a)
 				}
 			}
 			if (!stop) {
-				if constexpr (MODE == MODE_PRE) { if (s == 0) a.colmax[tbase + t0 + i] = (uint8_t)colmax; }
+				if constexpr (MODE == MODE_PRE) {
+					if (s == 0) { if constexpr (WORD) a.colmax_w[tbase + t0 + i] = (uint16_t)colmax; else a.colmax[tbase + t0 + i] = (uint8_t)colmax; }
+				}
 				if (colmax == terminate) stop = true;
 			}
 			ci++;
@@ -302,9 +305,11 @@ __global__ void __launch_bounds__(64) k_striped(StripedArgs a)
 		if (stop) {
 			const int score = (!WORD && overflow) ? 255 : maxv;
 			if constexpr (MODE == MODE_PRE) {
-				if (overflow) {
-					// Q1: the overflowing column and everything after it stay 0 (calloc'd array, sswNew.cpp:282)
-					for (int c = (ci - 1) + s; c < refLen; c += 16) a.colmax[tbase + t0 + c] = 0;
+				if constexpr (!WORD) {
+					if (overflow) {
+						// Q1: the overflowing column and everything after it stay 0 (calloc'd array, sswNew.cpp:282)
+						for (int c = (ci - 1) + s; c < refLen; c += 16) a.colmax[tbase + t0 + c] = 0;
+					}
 				}
 				if (s == 0) a.max_out[unit] = score;
 				phase = -1;
@@ -364,7 +369,7 @@ static hipError_t launch_striped_t(const StripedLaunch& L, hipStream_t st)
 	if (err != hipSuccess) return err;
 	StripedArgs a;
 	a.tcodes = L.tcodes; a.qcodes = L.qcodes; a.probs = L.probs; a.nprob = L.nprob; a.counter = L.counter;
-	a.lut = L.lut; a.s4 = s4; a.colmax = L.colmax; a.max_out = L.max_out; a.ends = L.ends;
+	a.lut = L.lut; a.s4 = s4; a.colmax = L.colmax; a.colmax_w = L.colmax_w; a.max_out = L.max_out; a.ends = L.ends;
 	// enough one-wave workgroups to fill the chip at the LDS-limited occupancy; the queue balances the rest
 	int per_cu = (int)((160 * 1024) / shmem);
 	if (per_cu < 1) per_cu = 1;
@@ -376,17 +381,13 @@ static hipError_t launch_striped_t(const StripedLaunch& L, hipStream_t st)
 	return hipGetLastError();
 }
 
-#if 0
-	hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), shmem, st, a);
-	return hipGetLastError();
-}
-#endif
-
 hipError_t launch_striped(StripedMode mode, bool word, bool quirk, const StripedLaunch& a, hipStream_t st)
 {
 	switch (mode) {
 	case MODE_PRE:
-		return launch_striped_t<MODE_PRE, false, true>(a, st);      // the 16-bit pre-align path is dead code (Q1)
+		// (the reference's 16-bit pre-align kernel is dead code (Q1); the word variant serves the ssw.h shim, which needs the
+		//  column maxima of sw_sse2_word for the sub-optimal score of alignments that overflow 8 bits)
+		return word ? launch_striped_t<MODE_PRE, true, false>(a, st) : launch_striped_t<MODE_PRE, false, true>(a, st);
 	case MODE_MAX1:
 		return word ? launch_striped_t<MODE_MAX1, true, false>(a, st) : launch_striped_t<MODE_MAX1, false, false>(a, st);
 	case MODE_ALIGN:

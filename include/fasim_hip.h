@@ -65,13 +65,19 @@ int fasim_calc_score_once(fasim_engine* e, const char* target, int32_t n, int32_
 /* ssw_pre_align() (ssw.h:128, sswNew.cpp:1309) behind Aligner::preAlign's base translation
  * (ssw_cpp.cpp:394-415): out_cols[n] = per-column maxima incl. the reference's Q1/Q2/Q3 behaviour. */
 int fasim_ssw_pre_align(fasim_engine* e, const char* target, int32_t n, int32_t* out_cols);
+/* column maxima of the reference's 16-bit kernels (sw_sse2_word, sswNew.cpp:893-1069; same DP as the unreachable
+ * sw_sse2_word_once, :698): 8 stripes, no overflow rule, no signed-compare quirk.  Used by the ssw.h shim
+ * (include/ssw.h) for the sub-optimal score of alignments whose score overflows 8 bits.                */
+int fasim_ssw_colmax_word(fasim_engine* e, const char* target, int32_t n, int32_t* out_cols);
 /* peak picking of Aligner::preAlign (ssw_cpp.cpp:427-572) on a column-max array (host logic).     */
 int fasim_pick_candidates(const int32_t* cols, int32_t n, int32_t threshold,
                           int32_t* out_score, int32_t* out_pos, int32_t cap, int32_t* count);
 /* ssw_align() (ssw.h:118, sswNew.cpp:1446) behind Aligner::Align (ssw_cpp.cpp:599-643).           */
 typedef struct fasim_alignment {
 	int32_t sw_score, ref_begin, ref_end, query_begin, query_end;
-	int32_t cigar_len;                 /* number of BAM-encoded ops in cigar[]                      */
+	int32_t cigar_len;                 /* number of BAM-encoded ops in cigar[]; -1 (with sw_score 0): the
+	                                      reference's ssw_align returns NULL here (banded_sw finds no path,
+	                                      sswNew.cpp:1535-1538), which its callers treat as score 0      */
 	uint32_t cigar[256];               /* (len<<4)|op, op 0=M 1=I 2=D (ssw.h:174)                   */
 } fasim_alignment;
 int fasim_ssw_align(fasim_engine* e, const char* window, int32_t n, fasim_alignment* out);
@@ -91,7 +97,10 @@ typedef struct fasim_triplex {
 	int32_t stari, endi, starj, endj, strand, reverse, rule, nt;
 	float   score, identity, tri_score;
 	int32_t seg, enc;                   /* provenance: segment index, encoding index                 */
-	int32_t reserved;
+	int32_t genome_shift;               /* added to start_genome for THIS record's genome coordinates; 0 from
+	                                       fasim_scan.  Only the B1-compatible reader (--accumulate-records) sets it:
+	                                       the reference patches each FASTA record's triplexes with that record's
+	                                       own start (Fasim-LongTarget.cpp:141-149)                         */
 	int64_t tfo_off, tts_off;           /* offsets of stri_align / strj_align in pool                */
 } fasim_triplex;
 
@@ -126,6 +135,26 @@ typedef struct fasim_result {
  * the reference.  seg_count < 0 = all remaining.  Used unsharded (1 GPU) or per rank (multi-GPU).   */
 int fasim_scan(fasim_engine* e, const char* dna, int64_t dna_len, int64_t seg_first, int64_t seg_count,
                const fasim_params* p, fasim_result** out);
+/* Multi-lncRNA batch (BASELINE config 4: many lncRNAs x one genome).  The reference holds ONE RNA per run
+ * (readRna(), Fasim-LongTarget.cpp:174-200) and is started once per lncRNA; here the DNA record stays resident
+ * and every (lncRNA, batch of segments) pair is one work item of the same queue, so consecutive lncRNAs overlap
+ * instead of paying a ramp-up and a drain each.  out[q] receives the records of rnas[q] exactly as fasim_scan
+ * would return them for that query alone (free each with fasim_result_free).  dna == NULL scans the resident
+ * record (fasim_load_dna).  Afterwards the engine's current query is rnas[nq-1].  Per-result stats.t_total_s is
+ * the wall clock from the start of that query's first batch to the end of its last one (neighbours overlap). */
+int fasim_scan_queries(fasim_engine* e, const char* const* rnas, const int32_t* rna_lens, int32_t nq,
+                       const char* dna, int64_t dna_len, int64_t seg_first, int64_t seg_count,
+                       const fasim_params* p, fasim_result** out /* [nq] */);
+/* Host half of the path's one exchange step: concatenates the records of `nparts` shards in the
+ * order given and rebases their pool offsets.  Shards are contiguous segment ranges, so rank order IS the
+ * reference's canonical (segment, encoding, fastSIM rank) order, which cluster_triplex()'s unstable sort needs.
+ * The result owns its memory (fasim_result_free); stats are zero. */
+int fasim_merge_results(const fasim_triplex* const* recs, const int64_t* counts, const char* const* pools,
+                        const int64_t* pool_lens, int32_t nparts, fasim_result** out);
+/* In-place form for a gather that receives every shard's records and pool directly at their final positions of one
+ * flat buffer (what gather_results() of the Python package does over RCCL): adds `delta` (= the bytes of pool that
+ * precede this shard's pool) to the pool offsets of `count` records. */
+int fasim_rebase_offsets(fasim_triplex* recs, int64_t count, int64_t delta);
 /* Optional: upload a DNA record once and keep it resident in HBM (and a host copy for the string work);
  * afterwards fasim_scan(e, NULL, 0, ...) scans the resident record without any H2D copy of the sequence. */
 int fasim_load_dna(fasim_engine* e, const char* dna, int64_t dna_len);
@@ -142,7 +171,23 @@ int fasim_tfosorted(const fasim_triplex* recs, int64_t count, const char* pool, 
  * class `level` (the reference writes levels 1 and 2, :832).  Clusters the records itself; dna_len = record length. */
 int fasim_tfoclass(const fasim_triplex* recs, int64_t count, int32_t level, const char* chr, int64_t start_genome,
                    int64_t dna_len, const char* rna_name, const fasim_params* p, char** text, int64_t* text_len);
+/* The same two with a flags word.  FASIM_TAIL_CLAMP_CLUSTER: when a triplex mid-point lies within -ds of the query
+ * start, cluster_triplex() of the reference indexes std::map<size_t,...> with a negative number and never terminates
+ * (Fasim-LongTarget.cpp:641-688; needs -lg below about 2*-ds).  Without the flag such input is refused
+ * (FASIM_E_UNSUPPORTED); with it the positions before the query start are treated as non-existent, which is what the
+ * reference's arithmetic means and gives a defined, terminating result (identical to the reference wherever the
+ * reference terminates). */
+#define FASIM_TAIL_CLAMP_CLUSTER 1
+int fasim_tfosorted_ex(const fasim_triplex* recs, int64_t count, const char* pool, int64_t pool_len,
+                       const char* chr, int64_t start_genome, const fasim_params* p, int32_t flags,
+                       char** text, int64_t* text_len);
+int fasim_tfoclass_ex(const fasim_triplex* recs, int64_t count, int32_t level, const char* chr, int64_t start_genome,
+                      int64_t dna_len, const char* rna_name, const fasim_params* p, int32_t flags,
+                      char** text, int64_t* text_len);
 void fasim_free(void* p);
+/* ingest helper: upper-cases a DNA record in place (soft-masked genomes such as UCSC hg38 carry repeats in lower
+ * case; the reference does not upper-case and treats such letters as unknown, rules.h:286-312, 82-83). */
+void fasim_upper_case(char* seq, int64_t n);
 
 /* deterministic synthetic DNA (splitmix64, 2 bits/base; same stream as tools/synth.py) */
 void fasim_synth_dna(char* out, int64_t n, uint64_t seed);

@@ -31,17 +31,18 @@ def h19(golden_dir):
 
 
 def test_raw_kernels_against_reference_vectors(mod, engine, golden_dir):
-    """S = calc_score_once, P = ssw_pre_align, A = ssw_align on the reference's own outputs (batch.rsp)."""
+    """S = calc_score_once, P = ssw_pre_align, K = Aligner::preAlign's candidate list (fasim_pick_candidates on the
+    column maxima of the HIP path), A = ssw_align on the reference's own outputs (batch.rsp)."""
     reqs = open(os.path.join(golden_dir, "batch.req")).read().splitlines()
     rsps = open(os.path.join(golden_dir, "batch.rsp")).read().splitlines()
     by_query = {}
     for rq, rs in zip(reqs, rsps):
         f = rq.split(" ")
         by_query.setdefault(f[1], []).append((f, rs.split(" ")))
-    checked = {"S": 0, "P": 0, "A": 0}
+    checked = {"S": 0, "P": 0, "K": 0, "A": 0}
     for q, items in by_query.items():
         engine.set_query(q.encode())
-        targets = [f[2].encode() for f, _ in items if f[0] in "SP"]
+        targets = [f[2].encode() for f, _ in items if f[0] in "SPK"]
         if targets:
             uniq = sorted(set(targets))
             cols, s1 = engine.pre_align_batch(uniq)
@@ -63,6 +64,10 @@ def test_raw_kernels_against_reference_vectors(mod, engine, golden_dir):
                 else:
                     got = (a.sw_score, a.ref_begin, a.ref_end, a.query_begin, a.query_end)
                     assert got == exp and (a.cigar_string() or "*") == g[6], ("A", q[:40], f[2][:40], got, exp)
+            elif f[0] == "K":
+                got = mod.pick_candidates(cmap[t], int(f[3]))
+                vals = [int(x) for x in g[2:]]
+                assert len(got) == int(g[1]) and got == list(zip(vals[0::2], vals[1::2])), ("K", q[:40], f[2][:40])
             else:
                 continue
             checked[f[0]] += 1
@@ -367,3 +372,202 @@ def test_live_reference_10kb_query_ntmax(mod, engine, tmp_path):
     assert res.stats["candidates"] == sum(u["ncand"] for u in units)
     assert res.triplexes() == _expected_triplexes(units)
     assert sum(u["stage1"] >= 251 for u in units) > 0, "the case must exercise byte overflow"
+
+
+# ---- the reference's own ssw.h ABI (include/ssw.h) ---------------------------------------------------------------
+SHIM_PROBE = os.path.join(entry.ROOT, "oracle", "_ref", "shim_probe")
+
+
+def test_ssw_h_shim_runs_reference_wrapper(golden_dir):
+    """oracle/_ref/shim_probe = the probe + the reference's UNCHANGED C++ wrapper (ssw_cpp.cpp), linked against the
+    ssw_init / ssw_pre_align / ssw_align / init_destroy / align_destroy of libfasim_hip.so in place of the reference's
+    sswNew.cpp (oracle/Makefile).  On the reference's own request file it must give the reference's own answers."""
+    if not os.access(SHIM_PROBE, os.X_OK):
+        pytest.skip("oracle/_ref/shim_probe not present (built by `make -C oracle ref` where /root/reference exists)")
+    req = open(os.path.join(golden_dir, "batch.req"), "rb").read()
+    out = subprocess.run([SHIM_PROBE, "batch"], input=req, check=True, stdout=subprocess.PIPE).stdout
+    got = out.decode().splitlines()
+    exp = open(os.path.join(golden_dir, "batch.rsp")).read().splitlines()
+    assert len(got) == len(exp)
+    kinds = {}
+    for g, e in zip(got, exp):
+        if e.startswith("A 0 "):        # nothing aligned: the reference's coordinates there come from reading ref[-1]
+            assert g.split(" ")[1] == "0"
+        else:
+            assert g == e, (g[:120], e[:120])
+        kinds[e[0]] = kinds.get(e[0], 0) + 1
+    assert kinds["P"] >= 50 and kinds["K"] >= 50 and kinds["A"] >= 50, kinds
+
+
+def test_ssw_h_abi_through_ctypes(mod, oracle_build):
+    """The five symbols called directly with the reference's calling convention (ssw_cpp.cpp:394-440, 605-640):
+    calloc'd profile borrowing read/mat, calloc'd int[refLen] freed by the caller, calloc'd s_align freed with
+    align_destroy, NULL + stderr for a scoring the engine does not implement."""
+    import ctypes as C
+    L = mod.lib()
+
+    class SAlign(C.Structure):
+        _fields_ = [("score1", C.c_uint16), ("score2", C.c_uint16), ("ref_begin1", C.c_int32), ("ref_end1", C.c_int32),
+                    ("read_begin1", C.c_int32), ("read_end1", C.c_int32), ("ref_end2", C.c_int32),
+                    ("cigar", C.POINTER(C.c_uint32)), ("cigarLen", C.c_int32)]
+    L.ssw_init.restype = C.c_void_p
+    L.ssw_init.argtypes = [C.POINTER(C.c_int8), C.c_int32, C.POINTER(C.c_int8), C.c_int32, C.c_int8]
+    L.init_destroy.argtypes = [C.c_void_p]
+    L.init_destroy.restype = None
+    L.ssw_pre_align.restype = C.POINTER(C.c_int)
+    L.ssw_pre_align.argtypes = [C.c_void_p, C.POINTER(C.c_int8), C.c_int32, C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint16, C.c_int32, C.c_int32, C.c_int]
+    L.ssw_align.restype = C.POINTER(SAlign)
+    L.ssw_align.argtypes = [C.c_void_p, C.POINTER(C.c_int8), C.c_int32, C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint16, C.c_int32, C.c_int32]
+    L.align_destroy.argtypes = [C.POINTER(SAlign)]
+    L.align_destroy.restype = None
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+
+    o = helpers.Oracle(oracle_build)
+    code = {65: 0, 67: 1, 71: 2, 84: 3}
+    q = synth.random_rna(777, 21)
+    t = synth.planted_dna(900, 22, q, every=200, max_len=110)
+    w = t[:150]
+
+    def codes(b):
+        return (C.c_int8 * len(b))(*[code.get(c, 4) for c in b])
+    mat = (C.c_int8 * 25)(*[(5 if (i == j and i < 4) else -4) for i in range(5) for j in range(5)])
+    cq = codes(q)
+    prof = L.ssw_init(cq, len(q), mat, 5, 2)
+    assert prof
+    cols = L.ssw_pre_align(prof, codes(t), len(t), 16, 4, 0x0f, 0, 32767, 15, 0)
+    assert cols and [cols[i] for i in range(len(t))] == o.pre_align(q, t)
+    libc.free(C.cast(cols, C.c_void_p))                         # the caller frees it (ssw_cpp.cpp:440)
+    a = L.ssw_align(prof, codes(w), len(w), 16, 4, 0x0f, 0, 32767, 15)
+    assert a
+    five, cig = o.align(q, w)
+    r = a.contents
+    assert (r.score1, r.ref_begin1, r.ref_end1, r.read_begin1, r.read_end1) == five
+    assert helpers.cigar_to_string([r.cigar[i] for i in range(r.cigarLen)]) == cig
+    # sub-optimal score (sswNew.cpp:641-665): best column maximum outside +-maskLen of ref_end1
+    pc = o.pre_align(q, w)
+    best, at = 0, 0
+    for i in list(range(0, max(0, r.ref_end1 - 15))) + list(range(min(len(w), r.ref_end1 + 15) + 1, len(w))):
+        if pc[i] > best:
+            best, at = pc[i], i
+    assert (r.score2, r.ref_end2) == (best, at)
+    L.align_destroy(a)
+    # flag 0: scores and end positions only
+    a = L.ssw_align(prof, codes(w), len(w), 16, 4, 0, 0, 32767, 15)
+    assert a and a.contents.ref_begin1 == -1 and a.contents.cigarLen == 0 and not a.contents.cigar
+    L.align_destroy(a)
+    # a scoring the engine does not implement: NULL (+ message on stderr), the reference's error convention
+    assert not L.ssw_align(prof, codes(w), len(w), 12, 4, 0x0f, 0, 32767, 15)
+    assert not L.ssw_pre_align(prof, codes(t), len(t), 16, 2, 0x0f, 0, 32767, 15, 0)
+    L.init_destroy(prof)
+
+
+# ---- BASELINE config 4: many lncRNAs x one genome record, segments sharded -----------------------------------------
+def _gz(golden_dir, name):
+    return helpers.gunzip(os.path.join(golden_dir, name))
+
+
+def _cfg4_inputs():
+    dna_masked = synth.genome_like(240000, 4004)
+    rnas = [synth.random_rna(3000, k) for k in (1, 2, 3, 4)]
+    return dna_masked, rnas
+
+
+def test_config4_multi_lncrna_sharded_scan(mod, golden_dir):
+    """4 synthetic 3 kb lncRNAs x a 240 kb genome-like record (N gaps incl. whole segments, soft-masking upper-cased as
+    `--upper` does, purine tracts), scanned as 3 contiguous segment shards with fasim_scan_queries over the RESIDENT
+    record and merged natively: byte-identical to the reference CLI run once per lncRNA (tests/golden/cfg4_q*.gz)."""
+    dna_masked, rnas = _cfg4_inputs()
+    dna = dna_masked.upper()
+    assert dna != dna_masked and b"N" * 5000 in dna
+    p = mod.default_params(cLength=40)
+    e = mod.Engine(0)
+    e.load_dna(dna)
+    nseg = mod.segment_count(len(dna), p)
+    cuts = [0, nseg // 3, 2 * nseg // 3, nseg]
+    shards = [e.scan_queries(rnas, None, p, cuts[i], cuts[i + 1] - cuts[i]) for i in range(3)]
+    whole = e.scan_queries(rnas, None, p)
+    for q in range(4):
+        merged = mod.merge_results([shards[i][q] for i in range(3)])
+        assert merged.recs == whole[q].recs and merged.pool == whole[q].pool
+        assert mod.tfosorted(merged, "chrG", 1, p) == _gz(golden_dir, f"cfg4_q{q + 1}.TFOsorted.gz")
+        for level in (1, 2):
+            assert mod.tfoclass(merged, level, "chrG", 1, len(dna), f"syn3k_{q + 1}", p) == _gz(golden_dir, f"cfg4_q{q + 1}.TFOclass{level}.gz")
+        assert whole[q].stats["segments_skipped"] > 0 and whole[q].stats["units"] > 0
+    # the batch returns, per lncRNA, exactly what a scan of that lncRNA alone returns (here: host buffer, streamed ingest)
+    e.set_query(rnas[2])
+    alone = e.scan(dna, p)
+    assert alone.recs == whole[2].recs and alone.pool == whole[2].pool
+    assert sum(alone.stats[k] for k in ("units", "candidates")) == sum(whole[2].stats[k] for k in ("units", "candidates"))
+    e.close()
+
+
+def test_cli_multi_lncrna_devices_upper(golden_dir, tmp_path):
+    """The driver end to end on config 4 in miniature: soft-masked DNA + --upper, four lncRNAs in one -f2 file, the
+    record cut into three device shards (--devices 0,0,0: three engines on the one GPU of the test box): the three
+    output files of every lncRNA equal the reference's."""
+    exe = os.path.join(entry.PKG_DIR, "fasim")
+    dna_masked, rnas = _cfg4_inputs()
+    synth.write_fasta(str(tmp_path / "dna.fa"), f"syn|chrG|1-{len(dna_masked)}", dna_masked)
+    with open(tmp_path / "four.fa", "wb") as f:
+        for k, r in enumerate(rnas):
+            f.write(f">syn3k_{k + 1}\n".encode() + r[:1700] + b"\n" + r[1700:] + b"\n")
+    (tmp_path / "out").mkdir()
+    r = subprocess.run([exe, "-f1", "dna.fa", "-f2", "four.fa", "-O", "out/", "-lg", "40", "--upper", "--devices", "0,0,0", "--stats"],
+                       cwd=tmp_path, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    assert b"end to end" in r.stderr and b"3 device shard" in r.stderr
+    for k in range(1, 5):
+        assert (tmp_path / "out" / f"syn-syn3k_{k}-dna-TFOsorted").read_bytes() == _gz(golden_dir, f"cfg4_q{k}.TFOsorted.gz")
+        for level in (1, 2):
+            assert (tmp_path / "out" / f"syn-syn3k_{k}-dna-TFOclass{level}-15-40").read_bytes() == _gz(golden_dir, f"cfg4_q{k}.TFOclass{level}.gz")
+
+
+def test_cli_devices_sharded_identical_to_unsharded(golden_dir, tmp_path):
+    exe = os.path.join(entry.PKG_DIR, "fasim")
+    for f in ("H19.fa", "planted40k.fa"):
+        (tmp_path / f).write_bytes(open(os.path.join(golden_dir, f), "rb").read())
+    (tmp_path / "out").mkdir()
+    subprocess.run([exe, "-f1", "planted40k.fa", "-f2", "H19.fa", "-O", "out/", "-lg", "40", "--devices", "0,0,0"], cwd=tmp_path, check=True,
+                   stdout=subprocess.DEVNULL)
+    assert (tmp_path / "out" / "syn-H19-planted40k-TFOsorted").read_bytes() == open(os.path.join(golden_dir, "planted40k.TFOsorted"), "rb").read()
+    for level in (1, 2):
+        got = (tmp_path / "out" / f"syn-H19-planted40k-TFOclass{level}-15-40").read_bytes()
+        assert got == open(os.path.join(golden_dir, f"planted40k.TFOclass{level}"), "rb").read()
+
+
+def test_cli_accumulate_records_is_bug_compatible(golden_dir, tmp_path):
+    """--accumulate-records reproduces the reference's reader on a multi-record DNA file (defect B1): record 2 is scanned
+    as record 1 + record 2, its header is parsed with the stale field counter (start 0, chr of record 1), and all
+    triplexes land in one output set named after record 1."""
+    exe = os.path.join(entry.PKG_DIR, "fasim")
+    for f in ("H19.fa", "b1_two.fa"):
+        (tmp_path / f).write_bytes(open(os.path.join(golden_dir, f), "rb").read())
+    (tmp_path / "out").mkdir()
+    subprocess.run([exe, "-f1", "b1_two.fa", "-f2", "H19.fa", "-O", "out/", "-lg", "40", "--accumulate-records"], cwd=tmp_path, check=True,
+                   stdout=subprocess.DEVNULL)
+    assert (tmp_path / "out" / "hg19-H19-b1_two-TFOsorted").read_bytes() == open(os.path.join(golden_dir, "b1_two.TFOsorted"), "rb").read()
+    for level in (1, 2):
+        got = (tmp_path / "out" / f"hg19-H19-b1_two-TFOclass{level}-15-40").read_bytes()
+        assert got == open(os.path.join(golden_dir, f"b1_two.TFOclass{level}"), "rb").read()
+
+
+def test_cluster_guard_flag(mod, engine, h19, golden_dir):
+    """-lg below ~2*-ds lets a triplex mid-point fall within -ds of the query start, where the reference's clustering
+    never terminates: refused by default, defined result with TAIL_CLAMP_CLUSTER; inputs the reference handles are
+    unaffected by the flag."""
+    hdr, dna = synth.read_fasta(os.path.join(golden_dir, "planted40k.fa"))
+    _, chro, start = mod.parse_dna_header(hdr)
+    engine.set_query(h19)
+    p = mod.default_params(cLength=40)
+    res = engine.scan(dna, p)
+    gold = open(os.path.join(golden_dir, "planted40k.TFOsorted"), "rb").read()
+    assert mod.tfosorted(res, chro, start, p, mod.TAIL_CLAMP_CLUSTER) == gold
+    p2 = mod.default_params(cLength=20, cDistance=40)
+    res2 = engine.scan(dna, p2)
+    near_start = [t for t in res2.triplexes() if t[7] > 20 and (t[0] + t[1]) // 2 < 40]
+    if not near_start:
+        pytest.skip("no triplex within -ds of the query start in this fixture")
+    with pytest.raises(mod.FasimError):
+        mod.tfosorted(res2, chro, start, p2)
+    text = mod.tfosorted(res2, chro, start, p2, mod.TAIL_CLAMP_CLUSTER)
+    assert text.count(b"\n") > 10

@@ -18,15 +18,88 @@ def _mod():
 
 
 def test_library_exports_every_declared_symbol():
+    """Every function include/fasim_hip.h and include/ssw.h declare is exported by libfasim_hip.so (no compute calls)."""
     m = _mod()
     hdr = open(os.path.join(entry.ROOT, "include", "fasim_hip.h")).read()
     declared = set(re.findall(r"\b(fasim_[a-z_0-9]+)\s*\(", hdr))
     declared -= {"fasim_engine", "fasim_params", "fasim_alignment", "fasim_triplex", "fasim_result", "fasim_scan_stats"}
+    # the reference's own ABI (ssw.h:78-142): names as declared in include/ssw.h
+    ssw = open(os.path.join(entry.ROOT, "include", "ssw.h")).read()
+    ssw = re.sub(r"/\*.*?\*/", "", ssw, flags=re.S)
+    ssw_declared = set(re.findall(r"\b([a-z_]+)\s*\(const s_profile\* prof|\b(ssw_init|init_destroy|align_destroy)\s*\(", ssw))
+    ssw_declared = {a or b for a, b in ssw_declared} | {"encoded_ops"}
+    assert ssw_declared == {"ssw_init", "init_destroy", "ssw_align", "ssw_pre_align", "align_destroy", "encoded_ops"}, ssw_declared
     L = m.lib()
     assert declared, "header parse failed"
-    for name in sorted(declared):
+    for name in sorted(declared | ssw_declared):
         assert hasattr(L, name), f"libfasim_hip.so does not export {name}"
-    assert set(m.EXPORTS) == declared
+    assert set(m.EXPORTS) == declared | ssw_declared
+
+
+def test_ssw_h_layouts_match_the_reference_abi():
+    """include/ssw.h must describe the same s_align layout as the reference's ssw.h:48-58 (x86-64: 40 bytes, cigar at 24)."""
+    import ctypes as C
+
+    class SAlign(C.Structure):
+        _fields_ = [("score1", C.c_uint16), ("score2", C.c_uint16), ("ref_begin1", C.c_int32), ("ref_end1", C.c_int32),
+                    ("read_begin1", C.c_int32), ("read_end1", C.c_int32), ("ref_end2", C.c_int32),
+                    ("cigar", C.POINTER(C.c_uint32)), ("cigarLen", C.c_int32)]
+    assert C.sizeof(SAlign) == 40 and SAlign.cigar.offset == 24 and SAlign.cigarLen.offset == 32
+    # and the header spells the fields in that order
+    ssw = open(os.path.join(entry.ROOT, "include", "ssw.h")).read()
+    order = [ssw.index(f) for f in ("uint16_t score1", "uint16_t score2", "int32_t ref_begin1", "int32_t ref_end1",
+                                    "int32_t read_begin1", "int32_t read_end1", "int32_t ref_end2", "uint32_t* cigar", "int32_t cigarLen")]
+    assert order == sorted(order)
+
+
+def test_native_merge_rebases_offsets():
+    """fasim_merge_results (host half of the exchange step): concatenation in the order given, pool offsets rebased."""
+    import time
+    import ctypes as C
+    m = _mod()
+
+    def part(n, tag):
+        recs, pool = [], bytearray()
+        for i in range(n):
+            t = m.Triplex()
+            t.stari, t.endi, t.seg, t.enc = i, i + 10, tag, i % 48
+            t.tfo_off = len(pool)
+            pool += f"TFO{tag}_{i}".encode() + b"\0"
+            t.tts_off = len(pool)
+            pool += f"TTS{tag}_{i}".encode() + b"\0"
+            recs.append(bytes(t))
+        return m.ScanResult(b"".join(recs), bytes(pool), {})
+
+    parts = [part(5, 0), part(0, 1), part(7, 2)]
+    merged = m.merge_results(parts)
+    assert merged.count == 12 and merged.pool == b"".join(p.pool for p in parts)
+    tr = merged.triplexes()
+    assert [t[11] for t in tr] == [f"TFO0_{i}".encode() for i in range(5)] + [f"TFO2_{i}".encode() for i in range(7)]
+    assert [t[12] for t in tr][5] == b"TTS2_0"
+    assert m.merge_results([]).count == 0
+    # size of the 8-GPU exchange of the 50 Mb bench (8 x 265 583 records): the gather puts the shards at their final
+    # positions and only rebases the offsets in place (fasim_rebase_offsets) -- a few ms; the copying merge
+    # (fasim_merge_results, used for local shards) is bound by the page faults of its fresh buffers
+    big = part(1000, 3)
+    n_rec, reps = 265583, 8
+    recs = big.recs * (n_rec // 1000 + 1)
+    pool = big.pool * (n_rec // 1000 + 1)
+    shard = m.ScanResult(recs[:n_rec * C.sizeof(m.Triplex)], pool, {})
+    shards = [shard] * reps
+    ptrs = [s.pointers() for s in shards]
+    t0 = time.perf_counter()
+    out = m._merge_pointers(ptrs)
+    dt_merge = time.perf_counter() - t0
+    assert out.count == n_rec * reps
+    data = recs[:n_rec * C.sizeof(m.Triplex)] * reps
+    flat = C.create_string_buffer(data, len(data))
+    t0 = time.perf_counter()
+    for k in range(reps):
+        assert m.lib().fasim_rebase_offsets(C.addressof(flat) + k * n_rec * C.sizeof(m.Triplex), n_rec, k * len(pool)) == 0
+    dt_rebase = time.perf_counter() - t0
+    assert flat.raw == out.recs, "in-place rebase and copying merge must agree"
+    assert dt_rebase < 0.05, f"in-place rebase of 8 x 265583 records took {dt_rebase * 1e3:.1f} ms"
+    print(f"8 x {n_rec} records: in-place rebase {dt_rebase * 1e3:.1f} ms, copying merge {dt_merge * 1e3:.1f} ms")
 
 
 def test_no_device_fails_loudly():

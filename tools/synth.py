@@ -8,6 +8,10 @@ anywhere (the C++ driver implements the same generator: fasim-longtarget_amd/csr
                                    lncRNA windows under random rule encodings, so that high-scoring
                                    hits, byte overflows (Q1), signed-lazy-F cases (Q2) and gapped
                                    window alignments are common.
+    genome_like(n, seed, ..)       chromosome-like record (hg38 is not in the container): telomere N run,
+                                   N gaps from 1 nt to whole segments, soft-masked (lower-case) interspersed
+                                   repeats, microsatellites and purine / pyrimidine tracts (the sequence
+                                   class triplexes form on).  See the function for the exact recipe.
 """
 from __future__ import annotations
 
@@ -108,6 +112,58 @@ def planted_dna(n: int, seed: int, rna: bytes, every: int = 1500, min_len: int =
     return bytes(dna[:n])
 
 
+def genome_like(n: int, seed: int, every: int = 6000, telomere: int = 10000, soft_mask: bool = True) -> bytes:
+    """Chromosome-like synthetic DNA (stands in for hg38 chr1 in BASELINE configs 3-5; SURVEY.md 8(d) "planted").
+
+    Background: i.i.d. uniform ACGT (random_dna(n, seed)).  Features are laid over it left to right by a scalar
+    splitmix64 stream (seed * 7919 + 17); after each feature the walk skips 1 .. 2*every nt.  Feature mix:
+      40 %  interspersed repeat: 200-3000 nt of the background turned to lower case (soft-masking, as UCSC hg38)
+      25 %  microsatellite: a random unit of 1-6 nt repeated to 30-400 nt, 3 % of the copies mutated;
+            half of them lower case (simple repeats are soft-masked too)
+      23 %  purine or pyrimidine tract: 20-300 nt over {A,G} or {C,T}, 8 % impurities -- the low-complexity
+            class Hoogsteen / reverse-Hoogsteen rules map onto lncRNA motifs (byte overflow Q1 and the signed
+            lazy-F exit Q2 become common, as on real promoters)
+      10 %  small N gap of 1-50 nt (inside a segment: the separate stage-1 pass, N = -1 vs -4, Q4)
+       2 %  large N gap of 5 000-40 000 nt (whole 5 kb segments of N: same_seq() skips)
+    plus `telomere` N at the start when n >= 20 * telomere.  soft_mask=False returns the record upper-cased
+    (what `fasim --upper` scans, and what the reference must be given: it does not upper-case its input)."""
+    dna = bytearray(random_dna(n, seed))
+    rng = _Rng(seed * 7919 + 17)
+    if n >= 20 * telomere:
+        dna[:telomere] = b"N" * telomere
+    pos = (telomere if n >= 20 * telomere else 0) + rng.below(every)
+    while pos + 64 < n:
+        kind = rng.below(100)
+        if kind < 40:
+            ln = min(200 + rng.below(2801), n - pos)
+            dna[pos:pos + ln] = bytes(dna[pos:pos + ln]).lower()
+        elif kind < 65:
+            unit = bytes(b"ACGT"[rng.below(4)] for _ in range(1 + rng.below(6)))
+            ln = min(30 + rng.below(371), n - pos)
+            tract = bytearray((unit * (ln // len(unit) + 1))[:ln])
+            for _ in range(ln * 3 // 100):
+                tract[rng.below(ln)] = b"ACGT"[rng.below(4)]
+            if rng.below(2):
+                tract = bytearray(bytes(tract).lower())
+            dna[pos:pos + ln] = tract
+        elif kind < 88:
+            pair = b"AG" if rng.below(2) else b"CT"
+            ln = min(20 + rng.below(281), n - pos)
+            tract = bytearray(pair[rng.below(2)] for _ in range(ln))
+            for _ in range(ln * 8 // 100):
+                tract[rng.below(ln)] = b"ACGT"[rng.below(4)]
+            dna[pos:pos + ln] = tract
+        elif kind < 98:
+            ln = min(1 + rng.below(50), n - pos)
+            dna[pos:pos + ln] = b"N" * ln
+        else:
+            ln = min(5000 + rng.below(35001), n - pos)
+            dna[pos:pos + ln] = b"N" * ln
+        pos += ln + 1 + rng.below(2 * every)
+    out = bytes(dna[:n])
+    return out if soft_mask else out.upper()
+
+
 def write_fasta(path: str, header: str, seq: bytes) -> None:
     """single record, single sequence line (the reference reader is O(lines x length) and
     accumulates multi-record files: SURVEY.md B1)"""
@@ -139,5 +195,7 @@ if __name__ == "__main__":
         write_fasta(out, f"syn|chrP|1-{n}", planted_dna(n, seed, rna))
     elif kind == "rna":
         write_fasta(out, f"synrna{seed}", random_rna(n, seed))
+    elif kind in ("genome", "genome-upper"):
+        write_fasta(out, f"syn|chrG|1-{n}", genome_like(n, seed, soft_mask=(kind == "genome")))
     else:
-        raise SystemExit("usage: synth.py random|planted|rna n seed out.fa [rna.fa]")
+        raise SystemExit("usage: synth.py random|planted|rna|genome|genome-upper n seed out.fa [rna.fa]")
