@@ -135,8 +135,12 @@ __device__ __forceinline__ int fp_lane_offset(int lane) { return (lane >> 3) * F
 
 // PAIR = false: 256-thread workgroups, per-code int16 profile (43 KB) + one v_perm_b32 per row;
 // PAIR = true : 1024-thread workgroups, profile per pair of codes (156 KB), no perm
+// workgroup size of the non-PAIR variant: 512 threads = 8 waves share one 43 KB profile, so two workgroups (86 KB) put 4 waves
+// on every SIMD; with 256-thread workgroups LDS allowed only three (3 waves per SIMD), and the packed VALU ops issue ~15 %
+// slower at 3 waves per SIMD than at 4 (profiles/r02_valu_issue_bench.txt)
+constexpr int FWD_THREADS = 512;
 template <int RP, bool TAINT, bool PAIR>
-__global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves_per_eu(PAIR ? 4 : 3, 4))) k_align_fwd(FwdArgs a)
+__global__ void __launch_bounds__(PAIR ? 1024 : FWD_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) k_align_fwd(FwdArgs a)
 {
 	constexpr int SC = TAINT ? 2 * AL_SCALE : AL_SCALE;      // value scale; TAINT: bit 5 = taint, bits 0..4 = row tag
 	extern __shared__ __align__(16) uint8_t prof[];
@@ -416,16 +420,16 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st)
 	hipError_t err = hipMemsetAsync(a.counter, 0, sizeof(uint32_t), st);
 	if (err != hipSuccess) return err;
 	// (the host sizes the tasks so that there are about 3072 of them: one task per wave, workgroups are short-lived)
-	constexpr int WPB = PAIR ? 16 : 4;
+	constexpr int WPB = PAIR ? 16 : FWD_THREADS / 64;
 	long blocks = ((long)a.ntask + WPB - 1) / WPB;
-	const long cap = PAIR ? 256 : 256 * 3;
+	const long cap = PAIR ? 256 : 256 * (16 / WPB);
 	if (blocks > cap) blocks = cap;
 	const size_t lds = PAIR ? (size_t)FP_LDS : (size_t)6 * AL_CODE_STRIDE;
 	if (PAIR) {
 		static bool attr_set = false;
 		if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_align_fwd<RP, TAINT, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
 	}
-	hipLaunchKernelGGL((k_align_fwd<RP, TAINT, PAIR>), dim3((unsigned)blocks), dim3(PAIR ? 1024 : 256), lds, st, a);
+	hipLaunchKernelGGL((k_align_fwd<RP, TAINT, PAIR>), dim3((unsigned)blocks), dim3(PAIR ? 1024 : FWD_THREADS), lds, st, a);
 	return hipGetLastError();
 }
 

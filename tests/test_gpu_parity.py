@@ -462,6 +462,31 @@ def test_ssw_h_abi_through_ctypes(mod, oracle_build):
     L.init_destroy(prof)
 
 
+def test_reference_driver_with_longtarget_binding(golden_dir, tmp_path):
+    """oracle/_ref/fasim_ref_hipbind = the reference's UNCHANGED driver (main, readDna, printResult, cluster_triplex,
+    print_cluster) linked with the LongTarget() binding of INTEGRATION.md section 2 instead of its own: the reference's
+    front and back end on top of libfasim_hip.so write the reference's files."""
+    exe = os.path.join(entry.ROOT, "oracle", "_ref", "fasim_ref_hipbind")
+    if not os.access(exe, os.X_OK):
+        pytest.skip("oracle/_ref/fasim_ref_hipbind not present (built by `make -C oracle ref` where /root/reference exists)")
+    for name, dna, extra in (("demo_lg40", "testDNA.fa", ["-lg", "40"]), ("planted40k", "planted40k.fa", ["-lg", "40"]),
+                             ("demo_t1_r3", "testDNA.fa", ["-lg", "30", "-t", "1", "-r", "3"])):
+        wd = tmp_path / name
+        (wd / "out").mkdir(parents=True)
+        for f in ("H19.fa", dna):
+            (wd / f).write_bytes(open(os.path.join(golden_dir, f), "rb").read())
+        subprocess.run([exe, "-f1", dna, "-f2", "H19.fa", "-O", "out/"] + extra, cwd=wd, check=True, stdout=subprocess.DEVNULL)
+        outs = sorted(os.listdir(wd / "out"))
+        assert len(outs) == 3, outs
+        for f in outs:
+            data = (wd / "out" / f).read_bytes()
+            if f.endswith("-TFOsorted"):
+                assert data == open(os.path.join(golden_dir, name + ".TFOsorted"), "rb").read(), f
+            else:
+                level = f.split("-TFOclass")[1].split("-")[0]
+                assert data == open(os.path.join(golden_dir, f"{name}.TFOclass{level}"), "rb").read(), f
+
+
 # ---- BASELINE config 4: many lncRNAs x one genome record, segments sharded -----------------------------------------
 def _gz(golden_dir, name):
     return helpers.gunzip(os.path.join(golden_dir, name))
@@ -571,3 +596,32 @@ def test_cluster_guard_flag(mod, engine, h19, golden_dir):
         mod.tfosorted(res2, chro, start, p2)
     text = mod.tfosorted(res2, chro, start, p2, mod.TAIL_CLAMP_CLUSTER)
     assert text.count(b"\n") > 10
+
+
+# ---- BASELINE configs 3 and 5 on a chromosome-like record ------------------------------------------------------------
+@pytest.mark.parametrize("name,rna_src,kw", [
+    ("big_meg3", "MEG3.fa", dict()),
+    ("big_malat1", "MALAT1.fa", dict()),
+    ("big_neat1", "NEAT1.fa", dict()),
+    ("big_syn10k", None, dict(ntMax=1000)),
+])
+def test_genome_like_1mb_long_queries(mod, golden_dir, name, rna_src, kw):
+    """MEG3 / MALAT1 / NEAT1 (configs[2]) and a 10 kb lncRNA with -na 1000 (configs[4]) x a 1.2 Mb chromosome-like record
+    (telomere and whole-segment N runs, soft-masked repeats upper-cased, microsatellites, purine tracts): the three output
+    files equal the compiled reference's (tests/golden/big_*.gz, made by make_golden.py big)."""
+    dna = synth.genome_like(1200000, 3003, soft_mask=False)
+    rna = synth.read_fasta(os.path.join(golden_dir, rna_src))[1] if rna_src else synth.random_rna(10000, 515)
+    rna_name = rna_src[:-3] if rna_src else "syn10k"
+    p = mod.default_params(**kw)
+    e = mod.Engine(0)
+    e.set_query(rna)
+    e.load_dna(dna)
+    res = e.scan(None, p)
+    st = res.stats
+    assert st["segments_skipped"] > 0 and st["stage1_word_reruns"] > 0      # all-N segments skipped, segments with N take the stage-1 pass
+    assert mod.tfosorted(res, "chrG", 1, p) == _gz(golden_dir, name + ".TFOsorted.gz")
+    for level in (1, 2):
+        assert mod.tfoclass(res, level, "chrG", 1, len(dna), rna_name, p) == _gz(golden_dir, f"{name}.TFOclass{level}.gz")
+    print(f"{name}: {st['units']} units, {st['candidates']} candidates, hazard {st['hazard_units']}, overflow {st['stage2_overflow_units']}, "
+          f"rev_exact {st['rev_exact']}, replays {st['exact_replays']}, word reruns {st['align_word_reruns']}, {res.count} records, {st['t_total_s']:.2f} s")
+    e.close()

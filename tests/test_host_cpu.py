@@ -52,6 +52,18 @@ def test_ssw_h_layouts_match_the_reference_abi():
     assert order == sorted(order)
 
 
+def test_integration_md_binding_is_the_compiled_text():
+    """The LongTarget() binding printed in INTEGRATION.md section 2 is byte for byte what oracle/longtarget_binding.cpp
+    compiles into oracle/_ref/fasim_ref_hipbind (reference driver + this binding; run on the GPU box by test_gpu_parity)."""
+    md = open(os.path.join(entry.ROOT, "INTEGRATION.md")).read()
+    src = open(os.path.join(entry.ROOT, "oracle", "longtarget_binding.cpp")).read()
+    body = src.split("// >>> INTEGRATION.md section 2: begin\n")[1].split("// <<< INTEGRATION.md section 2: end")[0]
+    assert "void LongTarget(struct para &paraList" in body
+    assert "```cpp\n" + body + "```" in md, "INTEGRATION.md section 2 and oracle/longtarget_binding.cpp differ"
+    if os.path.isdir("/root/reference"):
+        assert os.access(os.path.join(entry.ROOT, "oracle", "_ref", "fasim_ref_hipbind"), os.X_OK), "run `make -C oracle ref`"
+
+
 def test_native_merge_rebases_offsets():
     """fasim_merge_results (host half of the exchange step): concatenation in the order given, pool offsets rebased."""
     import time

@@ -4,7 +4,7 @@
 // needs the issue cost of the instruction class they are made of (packed 16-bit integer VOP3P ops).  This program
 // measures, per instruction, the shader clocks one SIMD spends per wave64 instruction:
 //     cycles/instruction/SIMD = s_memtime ticks of one wave / (instructions of that wave x waves per SIMD)
-// for 1, 2, 4 and 8 waves per SIMD, every CU busy, 8 independent dependency chains per wave.
+// for 1 .. 8 waves per SIMD, every CU busy, 8 independent dependency chains per wave.
 // It also prints the effective clock (s_memtime ticks / wall time), which is below the 2.4 GHz peak under load.
 //
 // Build + run on the GPU box (output kept under profiles/):
@@ -108,22 +108,23 @@ int main()
 	CHECK(hipGetDeviceProperties(&prop, 0));
 	const int cus = prop.multiProcessorCount;
 	printf("# device %s (%s), %d CUs, clockRate %d kHz\n", prop.name, prop.gcnArchName, cus, prop.clockRate);
-	printf("# %d x %d instructions per wave, 8 independent chains, W waves per SIMD: workgroups of 256 W threads, one per CU (W = 8: two of 1024)\n",
+	printf("# %d x %d instructions per wave, 8 independent chains, W waves per SIMD = W workgroups of 256 threads per CU (grid = W x CUs)\n",
 		ITERS, PER_ITER);
 	printf("# cyc = median over waves of s_memtime ticks / (instructions per wave x W); GHz = ticks / wall time of the kernel\n");
-	printf("%-30s %9s %9s %9s %9s %8s\n", "instruction", "cyc W=1", "cyc W=2", "cyc W=4", "cyc W=8", "GHz W=4");
+	printf("%-30s %8s %8s %8s %8s %8s %8s %8s %8s\n", "instruction", "cyc W=1", "cyc W=2", "cyc W=3", "cyc W=4", "cyc W=5", "cyc W=6", "cyc W=8", "GHz W=4");
 	uint64_t* ticks = nullptr; uint32_t* sink = nullptr;
-	CHECK(hipMalloc(&ticks, sizeof(uint64_t) * cus * 32));
+	CHECK(hipMalloc(&ticks, sizeof(uint64_t) * cus * 64));
 	CHECK(hipMalloc(&sink, 64));
 	hipEvent_t e0, e1;
 	CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
 	const double instr = (double)ITERS * PER_ITER;
 	for (const Op& op : ops) {
-		double cyc[4] = { 0, 0, 0, 0 }, ghz = 0;
-		for (int wi = 0; wi < 4; wi++) {
-			const int W = 1 << wi;
-			const int threads = W == 8 ? 1024 : 256 * W;
-			const int blocks = W == 8 ? 2 * cus : cus;
+		double cyc[7] = { 0, 0, 0, 0, 0, 0, 0 }, wall[7] = { 0, 0, 0, 0, 0, 0, 0 }, ghz = 0;
+		const int Ws[7] = { 1, 2, 3, 4, 5, 6, 8 };
+		for (int wi = 0; wi < 7; wi++) {
+			const int W = Ws[wi];
+			// 256-thread workgroups (4 waves: one per SIMD, the shape of k_scan), W of them per CU
+			const int threads = 256, blocks = W * cus;
 			hipLaunchKernelGGL(op.k, dim3(blocks), dim3(threads), 0, 0, ticks, sink, 1u);     // warm-up
 			CHECK(hipDeviceSynchronize());
 			CHECK(hipEventRecord(e0, 0));
@@ -131,14 +132,17 @@ int main()
 			CHECK(hipEventRecord(e1, 0));
 			CHECK(hipDeviceSynchronize());
 			float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
-			std::vector<uint64_t> h((size_t)cus * 4 * W);
+			std::vector<uint64_t> h((size_t)blocks * (threads / 64));
 			CHECK(hipMemcpy(h.data(), ticks, sizeof(uint64_t) * h.size(), hipMemcpyDeviceToHost));
 			std::sort(h.begin(), h.end());
 			const double med = (double)h[h.size() / 2];
 			cyc[wi] = med / (instr * W);
+			// the same from the wall clock: ns of one SIMD per wave64 instruction (independent of the clock estimate)
+			wall[wi] = (double)ms * 1e6 / (instr * W);
 			if (W == 4) ghz = med / (ms * 1e-3) / 1e9;
 		}
-		printf("%-30s %9.2f %9.2f %9.2f %9.2f %8.2f\n", op.name, cyc[0], cyc[1], cyc[2], cyc[3], ghz);
+		printf("%-30s %8.2f %8.2f %8.2f %8.2f %8.2f %8.2f %8.2f %8.2f\n", op.name, cyc[0], cyc[1], cyc[2], cyc[3], cyc[4], cyc[5], cyc[6], ghz);
+		printf("%-30s %8.2f %8.2f %8.2f %8.2f %8.2f %8.2f %8.2f\n", "   ns per instruction (wall)", wall[0], wall[1], wall[2], wall[3], wall[4], wall[5], wall[6]);
 	}
 	printf("# reading: ~2 cyc = full rate (one wave64 instruction per 2 clocks and SIMD, MI355X_MICROARCH.md).\n");
 	return 0;
