@@ -74,7 +74,7 @@ class _Result(C.Structure):
 EXPORTS = ["fasim_params_default", "fasim_engine_create", "fasim_engine_destroy", "fasim_last_error", "fasim_set_option", "fasim_set_query",
            "fasim_calc_score_once", "fasim_ssw_pre_align", "fasim_ssw_colmax_word", "fasim_pick_candidates", "fasim_ssw_align", "fasim_pre_align_batch",
            "fasim_align_batch", "fasim_encode_unit", "fasim_scan", "fasim_scan_queries", "fasim_merge_results", "fasim_rebase_offsets", "fasim_load_dna", "fasim_result_free", "fasim_segment_count",
-           "fasim_tfosorted", "fasim_tfoclass", "fasim_tfosorted_ex", "fasim_tfoclass_ex", "fasim_upper_case", "fasim_free",
+           "fasim_tfosorted", "fasim_tfoclass", "fasim_tfosorted_ex", "fasim_tfoclass_ex", "fasim_tail_outputs", "fasim_upper_case", "fasim_free",
            "fasim_synth_dna",
            # the reference's own ssw.h ABI (include/ssw.h)
            "ssw_init", "init_destroy", "ssw_pre_align", "ssw_align", "align_destroy", "encoded_ops"]
@@ -131,6 +131,8 @@ def lib():
                                      C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
     L.fasim_tfoclass_ex.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_char_p, C.c_int64, C.c_int64, C.c_char_p,
                                     C.POINTER(Params), C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    L.fasim_tail_outputs.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_char_p, C.c_int64, C.c_int64, C.c_char_p,
+                                     C.POINTER(Params), C.c_int32] + [C.POINTER(C.c_void_p), C.POINTER(C.c_int64)] * 3
     L.fasim_upper_case.argtypes = [C.c_void_p, C.c_int64]
     L.fasim_upper_case.restype = None
     L.fasim_free.argtypes = [C.c_void_p]
@@ -497,6 +499,28 @@ def tfoclass(result: ScanResult, level: int, chr_name: str, start_genome: int, d
         return C.string_at(text, n.value)
     finally:
         L.fasim_free(text)
+
+
+def tail_outputs(result: ScanResult, chr_name: str, start_genome: int, dna_len: int, rna_name: str, params: Params | None = None,
+                 flags: int = 0):
+    """(-TFOsorted, -TFOclass1, -TFOclass2) bytes from one clustering of the records (fasim_tail_outputs)."""
+    L = lib()
+    p = params or default_params()
+    texts = [C.c_void_p() for _ in range(3)]
+    lens = [C.c_int64() for _ in range(3)]
+    rp, cnt, pp, plen = result.pointers()
+    args = []
+    for t, n in zip(texts, lens):
+        args += [C.byref(t), C.byref(n)]
+    rc = L.fasim_tail_outputs(rp or None, cnt, pp or C.addressof(_EMPTY_POOL), max(1, plen), chr_name.encode(), start_genome, dna_len,
+                              rna_name.encode(), C.byref(p), flags, *args)
+    if rc != 0:
+        raise FasimError(f"fasim_tail_outputs failed ({rc}): {L.fasim_last_error(None).decode()}")
+    try:
+        return tuple(C.string_at(t, n.value) for t, n in zip(texts, lens))
+    finally:
+        for t in texts:
+            L.fasim_free(t)
 
 
 def synth_dna(n: int, seed: int) -> bytes:

@@ -30,7 +30,7 @@ using namespace fasim;
 
 namespace {
 
-std::string g_last_error;
+thread_local std::string g_last_error;     // per thread: the CLI formats and writes outputs on background threads
 
 struct DevBuf {
 	void* p = nullptr; size_t cap = 0;
@@ -86,6 +86,7 @@ struct fasim_engine {
 	HeavyGate* gate = nullptr;            // shared by the workers of one fasim_scan (points at the parent's own_gate)
 	int host_threads_total = 1;
 	int opt_workers = 0, opt_seg_batch = 0;      // fasim_set_option overrides (0 = default / environment)
+	int opt_taper = -1, opt_gate = -1;           // (-1 = default / environment)
 	bool query_acgt = true;       // query holds only A,C,G,T: stage-1 and stage-2 scoring coincide on N-free segments
 	bool scan_v1 = false;         // FASIM_SCAN_V1=1: force the stripe-faithful kernels for stages 1 and 2
 	int host_threads = 1;
@@ -912,6 +913,8 @@ int fasim_set_option(fasim_engine* E, const char* key, int32_t value)
 	if (!E || !key) return fail(E, FASIM_E_ARG, "null argument");
 	if (!strcmp(key, "workers")) E->opt_workers = value > 0 ? value : 0;
 	else if (!strcmp(key, "seg_batch")) E->opt_seg_batch = value > 0 ? value : 0;
+	else if (!strcmp(key, "taper")) E->opt_taper = value;          // percent of the segments scanned in half-size batches at the end (-1: default)
+	else if (!strcmp(key, "heavy_gate")) E->opt_gate = value;      // k_scan / k_align_fwd launches in flight at once (0: no gate, -1: default)
 	else return fail(E, FASIM_E_ARG, "unknown option %s", key);
 	return FASIM_OK;
 }
@@ -1514,10 +1517,12 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 		const uint8_t* dna_dev = resident ? E->dna_res.as<uint8_t>() + shard_lo : nullptr;
 		(void)shard_hi;
 		const int tstride = (p.cutLength + 15) & ~15;
-		// Batches of ~512 segments x 48 encodings; several batches are in flight at once on worker engines (own HIP
+		// Batches of ~384 segments x 48 encodings; several batches are in flight at once on worker engines (own HIP
 		// stream + buffers + host thread), so the latency-bound kernels (stripe-faithful re-runs, tracebacks) and the
 		// host-side work of one batch overlap the VALU-bound kernels of another.
-		int64_t seg_batch = std::max<int64_t>(1, std::min<int64_t>(512, ((int64_t)8 << 30) / ((int64_t)4 * nenc * tstride)));
+		// (384 rather than 512: a 50 Mb record then gives 27 batches for the 10 workers instead of exactly two rounds of ten, which
+		//  made all workers finish their last batch together: tools/sweep_sched.py, profiles/r02_sched_sweep.txt)
+		int64_t seg_batch = std::max<int64_t>(1, std::min<int64_t>(384, ((int64_t)8 << 30) / ((int64_t)4 * nenc * tstride)));
 		const char* envb = getenv("FASIM_SEG_BATCH");
 		if (envb) seg_batch = std::max(1, atoi(envb));
 		if (E->opt_seg_batch > 0) seg_batch = E->opt_seg_batch;
@@ -1529,11 +1534,16 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 		// remaining / (g * workers), at least 64 segments) to shorten the tail of a scan; measured slower on the 50 Mb
 		// workload (every batch pays ~12 host round trips, so smaller batches cost more than the shorter tail saves).
 		static const double guided = [] { const char* e = getenv("FASIM_GUIDED"); return e ? atof(e) : 0.0; }();
+		// FASIM_TAPER=t (percent, default 0): the last t % of the segments go in half-size batches, so that the workers do not
+		// all finish their last batch at the same moment (shorter drain at the end of a scan)
+		static const int taper = [] { const char* e = getenv("FASIM_TAPER"); return e ? atoi(e) : 0; }();
+		const int taper_pct = E->opt_taper >= 0 ? E->opt_taper : taper;
 		std::vector<std::pair<int64_t, int64_t>> chunks;
 		{
 			int64_t b0 = seg_first; const int64_t b_end = seg_first + seg_count;
+			const int64_t taper_from = b_end - seg_count * taper_pct / 100;
 			while (b0 < b_end) {
-				int64_t len = seg_batch;
+				int64_t len = (taper_pct > 0 && b0 >= taper_from) ? std::max<int64_t>(1, seg_batch / 2) : seg_batch;
 				if (guided > 0) {
 					const int64_t g = (int64_t)((double)(b_end - b0) / (guided * nworkers)) + 1;
 					len = std::max<int64_t>(std::min<int64_t>(64, seg_batch), std::min<int64_t>(seg_batch, g));
@@ -1558,7 +1568,7 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 		for (int k = 0; k < nworkers - 1; k++) ws.push_back(E->workers[k]);
 		{
 			const char* envg = getenv("FASIM_HEAVY_GATE");      // heavy kernels in flight at once (0 = no gate)
-			E->own_gate.cap = envg ? atoi(envg) : 3;
+			E->own_gate.cap = E->opt_gate >= 0 ? E->opt_gate : (envg ? atoi(envg) : 3);
 		}
 		for (fasim_engine* w : ws) {
 			w->gate = (ws.size() > 1 && E->own_gate.cap > 0) ? &E->own_gate : nullptr;
@@ -1605,6 +1615,7 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 		for (size_t wi = 0; wi < ws.size(); wi++) if (wrc[wi]) { if (ws[wi] != E) E->err = ws[wi]->err; return wrc[wi]; }
 		// a multi-query call leaves the engine on its LAST query (documented in fasim_hip.h)
 		if (nq > 0 && E->rna != queries.back()) { int rc = fasim_set_query(E, queries.back().data(), (int)queries.back().size()); if (rc) return rc; }
+		const double t_merge = now_s();
 		std::vector<double> q0(nquery, 1e300), q1(nquery, 0.0);
 		for (size_t c = 0; c < items.size(); c++) {
 			const int q = items[c].q;
@@ -1614,14 +1625,17 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 		}
 		// per query: wall clock from the start of its first batch to the end of its last one (neighbouring queries overlap)
 		for (int q = 0; q < nquery; q++) qst[(size_t)q].t_total_s = nquery == 1 ? 0.0 : std::max(0.0, q1[q] - q0[q]);
+		if (g_prof.on) fprintf(stderr, "[fasim prof] scan tail: concatenating the batches              %.3f s\n", now_s() - t_merge);
 	}
 
 	if (nquery == 1) qst[0].t_total_s = now_s() - t_begin;
+	const double t_pack = now_s();
 	for (int q = 0; q < nquery; q++) {
 		const int rc = pack_result(E, all[(size_t)q], qst[(size_t)q], &outs[q]);
 		if (rc) { for (int k = 0; k < q; k++) { fasim_result_free(outs[k]); outs[k] = nullptr; } return rc; }
 	}
 	if (nquery == 1) outs[0]->stats.t_total_s = now_s() - t_begin;
+	if (g_prof.on) fprintf(stderr, "[fasim prof] scan tail: packing the records                        %.3f s\n", now_s() - t_pack);
 	if (g_prof.on) {
 		double tot = now_s() - t_begin;
 		fprintf(stderr, "[fasim prof] total %.3f s  stage2 %.3f  stage3 %.3f  host %.3f\n", tot, qst[0].t_stage2_s, qst[0].t_stage3_s, qst[0].t_host_s);
@@ -1751,6 +1765,24 @@ int fasim_tfoclass(const fasim_triplex* recs, int64_t count, int32_t level, cons
 	int64_t dna_len, const char* rna_name, const fasim_params* p, char** text, int64_t* text_len)
 {
 	return fasim_tfoclass_ex(recs, count, level, chr, start_genome, dna_len, rna_name, p, 0, text, text_len);
+}
+
+int fasim_tail_outputs(const fasim_triplex* recs, int64_t count, const char* pool, int64_t pool_len, const char* chr,
+	int64_t start_genome, int64_t dna_len, const char* rna_name, const fasim_params* p, int32_t flags,
+	char** tfosorted, int64_t* tfosorted_len, char** class1, int64_t* class1_len, char** class2, int64_t* class2_len)
+{
+	if ((count > 0 && (!recs || !pool)) || !chr || !rna_name || !p || count < 0 || !tfosorted || !tfosorted_len || !class1 || !class1_len ||
+		!class2 || !class2_len) return fail(nullptr, FASIM_E_ARG, "bad arguments");
+	*tfosorted = *class1 = *class2 = nullptr;
+	std::vector<HostTriplex> list;
+	int rc = records_to_list(recs, count, pool, pool_len, p, start_genome, flags, list);
+	if (rc != FASIM_OK) return rc;
+	// one clustering serves the three files (tfosorted_text clusters and orders the list; print_cluster only reads classes)
+	rc = text_out(tfosorted_text(list, chr, (long)start_genome, *p), tfosorted, tfosorted_len);
+	if (rc == FASIM_OK) rc = text_out(tfoclass_text(list, 1, chr, (long)start_genome, (long)dna_len, rna_name, *p), class1, class1_len);
+	if (rc == FASIM_OK) rc = text_out(tfoclass_text(list, 2, chr, (long)start_genome, (long)dna_len, rna_name, *p), class2, class2_len);
+	if (rc != FASIM_OK) { free(*tfosorted); free(*class1); free(*class2); *tfosorted = *class1 = *class2 = nullptr; }
+	return rc;
 }
 
 void fasim_upper_case(char* seq, int64_t n)

@@ -29,6 +29,8 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <deque>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -134,29 +136,29 @@ static void write_file(const std::string& path, const char* text, int64_t len)
 	of.write(text, (std::streamsize)len);
 }
 
-struct Timers { double parse = 0, scan = 0, tail = 0, write = 0; };
+struct Timers { double parse = 0, scan = 0, tail = 0, write = 0, tail_wait = 0; };
 
-// -TFOsorted + the two -TFOclass files of one lncRNA (printResult(), Fasim-LongTarget.cpp:797-836)
+// -TFOsorted + the two -TFOclass files of one lncRNA (printResult(), Fasim-LongTarget.cpp:797-836): one clustering, three texts
 static int write_outputs(const fasim_result* res, const std::string& stem, const std::string& chr, long start, int64_t dna_len,
 	const std::string& lnc_name, const fasim_params& p, int flags, Timers& tm)
 {
-	char* text = nullptr; int64_t len = 0;
+	char* text[3] = { nullptr, nullptr, nullptr }; int64_t len[3] = { 0, 0, 0 };
 	double t0 = now_s();
-	if (fasim_tfosorted_ex(res->recs, res->count, res->pool, res->pool_len, chr.c_str(), start, &p, flags, &text, &len) != FASIM_OK) { fprintf(stderr, "fasim: %s\n", fasim_last_error(nullptr)); return 1; }
+	if (fasim_tail_outputs(res->recs, res->count, res->pool, res->pool_len, chr.c_str(), start, dna_len, lnc_name.c_str(), &p, flags,
+		&text[0], &len[0], &text[1], &len[1], &text[2], &len[2]) != FASIM_OK) { fprintf(stderr, "fasim: %s\n", fasim_last_error(nullptr)); return 1; }
 	tm.tail += now_s() - t0; t0 = now_s();
-	write_file(stem + "-TFOsorted", text, len);
-	fasim_free(text);
+	write_file(stem + "-TFOsorted", text[0], len[0]);
+	for (int level = 1; level <= 2; level++)     // print_cluster x2 (:832-836): <prefix>-TFOclass<level>-<ds>-<lg> (:706)
+		write_file(stem + "-TFOclass" + std::to_string(level) + "-" + std::to_string(p.cDistance) + "-" + std::to_string(p.cLength), text[level], len[level]);
+	for (char* t : text) fasim_free(t);
 	tm.write += now_s() - t0;
-	for (int level = 1; level <= 2; level++) {   // print_cluster x2 (:832-836): <prefix>-TFOclass<level>-<ds>-<lg> (:706)
-		t0 = now_s();
-		if (fasim_tfoclass_ex(res->recs, res->count, level, chr.c_str(), start, dna_len, lnc_name.c_str(), &p, flags, &text, &len) != FASIM_OK) { fprintf(stderr, "fasim: %s\n", fasim_last_error(nullptr)); return 1; }
-		tm.tail += now_s() - t0; t0 = now_s();
-		write_file(stem + "-TFOclass" + std::to_string(level) + "-" + std::to_string(p.cDistance) + "-" + std::to_string(p.cLength), text, len);
-		fasim_free(text);
-		tm.write += now_s() - t0;
-	}
 	return 0;
 }
+
+// The host tail of record i (clustering, text, file writes) runs on its own thread while the devices already scan record
+// i+1; at most `kMaxPending` results wait to be written.
+static std::mutex g_out_mu;
+static int g_out_failed = 0;
 
 // Scans one DNA record with every lncRNA on every device: device d takes the d-th contiguous block of segments
 // (SURVEY 8(e)); per lncRNA the shard results are merged in shard order, which is the reference's canonical order.
@@ -274,6 +276,7 @@ int main(int argc, char* const* argv)
 	DnaRecord rec;
 	size_t nrec = 0;
 	int64_t total_nt = 0;
+	std::deque<std::thread> pending;
 	if (accumulate) {
 		// B1: tmpDNA is never cleared, so record k holds records 1..k; all triplexes go into ONE list that is printed with
 		// the first record's species / chr / start / length (main(), Fasim-LongTarget.cpp:133-166)
@@ -331,18 +334,32 @@ int main(int argc, char* const* argv)
 						(long long)s.candidates, (long long)s.align_calls, (long long)res[q]->count);
 				}
 				const std::string stem = outdir + "/" + rec.species + "-" + rnas[q].name + "-" + base + (all_records ? "." + rec.chr : std::string());
-				if (write_outputs(res[q], stem, rec.chr, rec.start, (int64_t)rec.seq.size(), rnas[q].name, p, tail_flags, tm)) return 1;
-				fasim_result_free(res[q]);
+				// tail + write on a background thread: the next record is parsed and scanned meanwhile
+				while (pending.size() >= 4) { pending.front().join(); pending.pop_front(); }
+				fasim_result* r = res[q];
+				const std::string chr = rec.chr, lname = rnas[q].name; const long start = rec.start; const int64_t dlen = (int64_t)rec.seq.size();
+				pending.emplace_back([=, &tm, &p]() {
+					Timers mine;
+					const int bad = write_outputs(r, stem, chr, start, dlen, lname, p, tail_flags, mine);
+					fasim_result_free(r);
+					std::lock_guard<std::mutex> lk(g_out_mu);
+					tm.tail += mine.tail; tm.write += mine.write; if (bad) g_out_failed = 1;
+				});
 			}
 			nrec++;
 		}
+		const double t_wait = now_s();
+		for (std::thread& t : pending) t.join();
+		pending.clear();
+		tm.tail_wait = now_s() - t_wait;
+		if (g_out_failed) return 1;
 	}
 	if (nrec == 0) { fprintf(stderr, "fasim: no record in DNA file %s\n", f1.c_str()); return 1; }
 	for (fasim_engine* e : engines) fasim_engine_destroy(e);
 	if (stats) {
 		const double total = now_s() - t_start;
-		fprintf(stderr, "[fasim] end to end %.3f s: parse %.3f, scan %.3f, tail %.3f, write %.3f (%zu DNA record(s), %lld nt, %zu lncRNA(s), %zu device shard(s)) = %.3f Mbp/s per lncRNA\n",
-			total, tm.parse, tm.scan, tm.tail, tm.write, nrec, (long long)total_nt, rnas.size(), engines.size(),
+		fprintf(stderr, "[fasim] end to end %.3f s: parse %.3f, scan %.3f, tail %.3f + write %.3f on background threads (%.3f s not hidden behind the next scan) (%zu DNA record(s), %lld nt, %zu lncRNA(s), %zu device shard(s)) = %.3f Mbp/s per lncRNA\n",
+			total, tm.parse, tm.scan, tm.tail, tm.write, tm.tail_wait, nrec, (long long)total_nt, rnas.size(), engines.size(),
 			(double)total_nt * (double)rnas.size() / total / 1e6);
 	}
 	std::cout << "finished normally" << std::endl;

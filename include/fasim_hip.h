@@ -51,8 +51,11 @@ int  fasim_engine_create(int device, fasim_engine** out);
 void fasim_engine_destroy(fasim_engine* e);
 const char* fasim_last_error(const fasim_engine* e);   /* e may be NULL: last global error */
 
-/* Tuning knobs (optional).  key "workers": batches kept in flight by fasim_scan (default 6, env FASIM_WORKERS);
- * key "seg_batch": segments per batch (default 512, env FASIM_SEG_BATCH).  value <= 0 restores the default. */
+/* Tuning knobs (optional).  key "workers": batches kept in flight by fasim_scan (default 10, env FASIM_WORKERS);
+ * key "seg_batch": segments per batch (default 384, env FASIM_SEG_BATCH); value <= 0 restores the default.
+ * key "taper": percent of the segments scanned in half-size batches at the end (default 0, env FASIM_TAPER);
+ * key "heavy_gate": k_scan / k_align_fwd launches in flight at once (default 3, env FASIM_HEAVY_GATE; 0 = no gate);
+ * -1 restores the default of the last two. */
 int fasim_set_option(fasim_engine* e, const char* key, int32_t value);
 
 /* Replaces ssw_init()/init_destroy() (ssw.h:78,83) and init_work() (stats.h:386): the lncRNA is
@@ -184,6 +187,12 @@ int fasim_tfosorted_ex(const fasim_triplex* recs, int64_t count, const char* poo
 int fasim_tfoclass_ex(const fasim_triplex* recs, int64_t count, int32_t level, const char* chr, int64_t start_genome,
                       int64_t dna_len, const char* rna_name, const fasim_params* p, int32_t flags,
                       char** text, int64_t* text_len);
+/* printResult() as a whole (Fasim-LongTarget.cpp:797-836): the -TFOsorted text and the two -TFOclass texts (levels 1 and 2)
+ * from ONE clustering of the records (the separate calls above each cluster again).  Free each text with fasim_free. */
+int fasim_tail_outputs(const fasim_triplex* recs, int64_t count, const char* pool, int64_t pool_len, const char* chr,
+                       int64_t start_genome, int64_t dna_len, const char* rna_name, const fasim_params* p, int32_t flags,
+                       char** tfosorted, int64_t* tfosorted_len, char** class1, int64_t* class1_len,
+                       char** class2, int64_t* class2_len);
 void fasim_free(void* p);
 /* ingest helper: upper-cases a DNA record in place (soft-masked genomes such as UCSC hg38 carry repeats in lower
  * case; the reference does not upper-case and treats such letters as unknown, rules.h:286-312, 82-83). */

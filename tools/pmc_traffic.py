@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Fold two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) into profiles/r01_pmc_traffic.json.
+"""Fold two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) into profiles/r0N_pmc_traffic.json.
 
 On the GPU box (counters in their own runs, no trace domains mixed in):
     export FASIM_WORKERS=1 FASIM_SEG_BATCH=1024
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f -- python3 bench.py --dna-mb 5 --warmup 0 --no-cpu-baseline
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -- python3 bench.py --dna-mb 5 --warmup 0 --no-cpu-baseline
-    python tools/pmc_traffic.py gpurun_out/pmc_f gpurun_out/pmc_w gpurun_out/bench_pmc.json > gpurun_out/r01_pmc_traffic.json
+    python tools/pmc_traffic.py gpurun_out/pmc_f gpurun_out/pmc_w gpurun_out/bench_pmc.json > gpurun_out/r0N_pmc_traffic.json
 
 FETCH_SIZE / WRITE_SIZE are reported in KB.  On gfx950 FETCH_SIZE counts 64 B per 128-B request (MI355X_MICROARCH.md,
 HBM / rocprofv3 section): fetch figures are doubled; the k_scan launch, which must read exactly units x tstride bytes
