@@ -66,6 +66,17 @@ class ScanStats(C.Structure):
                 ("exact_replays", C.c_int64), ("tries_skipped", C.c_int64)]
 
 
+class SimNode(C.Structure):
+    """struct fasim_sim_node: one entry of SIM's node list (vertex, sim.h:47-58)."""
+    _fields_ = [(k, C.c_int64) for k in ("score", "stari", "starj", "endi", "endj", "top", "bot", "left", "right")]
+
+    def astuple(self):
+        return tuple(getattr(self, k) for k, _ in self._fields_)
+
+
+SIM_K = 50
+
+
 class _Result(C.Structure):
     _fields_ = [("recs", C.POINTER(Triplex)), ("count", C.c_int64), ("pool", C.POINTER(C.c_char)), ("pool_len", C.c_int64),
                 ("stats", ScanStats)]
@@ -73,7 +84,7 @@ class _Result(C.Structure):
 
 EXPORTS = ["fasim_params_default", "fasim_engine_create", "fasim_engine_destroy", "fasim_last_error", "fasim_set_option", "fasim_set_query",
            "fasim_calc_score_once", "fasim_ssw_pre_align", "fasim_ssw_colmax_word", "fasim_pick_candidates", "fasim_ssw_align", "fasim_pre_align_batch",
-           "fasim_align_batch", "fasim_encode_unit", "fasim_scan", "fasim_scan_queries", "fasim_merge_results", "fasim_rebase_offsets", "fasim_load_dna", "fasim_result_free", "fasim_segment_count",
+           "fasim_align_batch", "fasim_encode_unit", "fasim_sim_forward_batch", "fasim_scan", "fasim_scan_queries", "fasim_merge_results", "fasim_rebase_offsets", "fasim_load_dna", "fasim_result_free", "fasim_segment_count",
            "fasim_tfosorted", "fasim_tfoclass", "fasim_tfosorted_ex", "fasim_tfoclass_ex", "fasim_tail_outputs", "fasim_upper_case", "fasim_free",
            "fasim_synth_dna",
            # the reference's own ssw.h ABI (include/ssw.h)
@@ -110,6 +121,8 @@ def lib():
     L.fasim_align_batch.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int32,
                                     C.POINTER(Alignment)]
     L.fasim_encode_unit.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_char_p, C.c_char_p]
+    L.fasim_sim_forward_batch.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int32,
+                                          C.POINTER(C.c_int64), C.POINTER(SimNode), C.POINTER(C.c_int32)]
     L.fasim_scan.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(Params),
                              C.POINTER(C.POINTER(_Result))]
     L.fasim_load_dna.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
@@ -400,6 +413,17 @@ class Engine:
         out = (Alignment * len(windows))()
         self._check(self._L.fasim_align_batch(self._h, blob, offs, lens, len(windows), out))
         return list(out)
+
+    def sim_forward(self, targets, min_scores):
+        """Forward sweep of classic SIM (-F, sim.h:506-571) for a batch of targets: per target the node list it leaves, as
+        tuples (score x10, stari, starj, endi, endj, top, bot, left, right) in list order."""
+        blob, offs, lens = self._pack(targets)
+        n = len(targets)
+        mins = (C.c_int64 * n)(*min_scores)
+        nodes = (SimNode * (n * SIM_K))()
+        counts = (C.c_int32 * n)()
+        self._check(self._L.fasim_sim_forward_batch(self._h, blob, offs, lens, n, mins, nodes, counts))
+        return [[nodes[k * SIM_K + x].astuple() for x in range(counts[k])] for k in range(n)]
 
     # --- the LongTarget() body ----------------------------------------------------------------------
     def load_dna(self, dna: bytes):

@@ -70,6 +70,22 @@ struct AlignOutDev {           // 32-byte header; the CIGAR ops go to a compact 
 	uint32_t cigar_off;   // offset in the cigar pool
 };
 
+// ---- row f3: forward sweep of classic SIM (sim.hip) ---------------------------------------------------
+struct SimEvent { uint32_t i, j; uint64_t key; };      // a cell above the threshold: row, column, (score + 2^20) << 26 | start_row << 13 | start_col
+struct SimFwdArgs {
+	const uint8_t* tcodes;      // [unit][tstride] target letters as codes A0 C1 G2 T3 other 4
+	const int32_t* unit_len;
+	int32_t tstride;
+	const uint8_t* qcodes;      // [m] query letters, same coding
+	int32_t m;
+	const int64_t* min_score;   // [unit] threshold of the first sweep (the reference compares the x10 scores with it, sim.h:567)
+	uint64_t* rowbuf;           // [unit][2][row_stride]: C and D of the last finished strip's bottom row
+	int64_t row_stride;
+	SimEvent* events;           // [unit][event_cap]
+	uint32_t event_cap;
+	uint32_t* event_count;      // [unit], zeroed by the caller; may exceed event_cap (then the caller retries with more room)
+};
+
 // packed 4-bit score table: entry q (0..5) of row t = score(t,q)+BIAS
 struct ScoreLut { uint32_t row[5]; };
 

@@ -1005,6 +1005,124 @@ int fasim_ssw_colmax_word(fasim_engine* E, const char* target, int32_t n, int32_
 	return FASIM_OK;
 }
 
+// ---- row f3: forward sweep of classic SIM ---------------------------------------------------------------------
+// addnode() (sim.h:99-148) over the events of one unit in row-major order: a known start point is updated (strictly larger
+// score moves the end point; the bounding box grows), a new one is appended or, with K nodes present, overwrites the first
+// node of lowest score whatever its own score is.
+static void sim_replay_nodes(const std::vector<SimEvent>& ev, std::vector<fasim_sim_node>& nodes)
+{
+	nodes.clear();
+	for (const SimEvent& e : ev) {
+		const int64_t c = (int64_t)(e.key >> 26) - ((int64_t)1 << 20);
+		const int64_t ci = (int64_t)((e.key >> 13) & 0x1fff), cj = (int64_t)(e.key & 0x1fff), i = e.i, j = e.j;
+		bool found = false;
+		for (fasim_sim_node& n : nodes) {
+			if (n.stari != ci || n.starj != cj) continue;
+			if (n.score < c) { n.score = c; n.endi = i; n.endj = j; }
+			if (n.top > i) n.top = i;
+			if (n.bot < i) n.bot = i;
+			if (n.left > j) n.left = j;
+			if (n.right < j) n.right = j;
+			found = true;
+			break;
+		}
+		if (found) continue;
+		const fasim_sim_node fresh = { c, ci, cj, i, j, i, i, j, j };
+		if ((int)nodes.size() == FASIM_SIM_K) {
+			size_t low = 0;
+			for (size_t d = 1; d < nodes.size(); d++) if (nodes[d].score < nodes[low].score) low = d;
+			nodes[low] = fresh;
+		} else nodes.push_back(fresh);
+	}
+}
+
+int fasim_sim_forward_batch(fasim_engine* E, const char* targets, const int64_t* offsets, const int32_t* lens, int32_t nprob,
+	const int64_t* min_scores, fasim_sim_node* nodes, int32_t* counts)
+{
+	int rc = need_query(E); if (rc) return rc;
+	if (!targets || !offsets || !lens || !min_scores || !nodes || !counts || nprob <= 0) return fail(E, FASIM_E_ARG, "bad arguments");
+	if (E->m > 8191) return fail(E, FASIM_E_UNSUPPORTED, "the SIM forward sweep holds start points in 13 bits: query of %d nt is too long", E->m);
+	HIPOK(hipSetDevice(E->device));
+	auto code = [](char c) -> uint8_t { switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return 4; } };
+	int maxlen = 1;
+	for (int k = 0; k < nprob; k++) {
+		if (lens[k] <= 0 || lens[k] > 8191) return fail(E, FASIM_E_UNSUPPORTED, "target %d: length %d outside 1..8191", k, lens[k]);
+		maxlen = std::max(maxlen, lens[k]);
+	}
+	const int tstride = (maxlen + 15) & ~15;
+	std::vector<uint8_t> tc((size_t)nprob * tstride, 4), qc((size_t)E->m);
+	for (int k = 0; k < nprob; k++) for (int c = 0; c < lens[k]; c++) tc[(size_t)k * tstride + c] = code(targets[offsets[k] + c]);
+	for (int i = 0; i < E->m; i++) qc[(size_t)i] = code(E->rna[(size_t)i]);
+	DevBuf d_tc, d_q, d_len, d_min, d_row, d_ev, d_cnt;
+	struct Release { std::vector<DevBuf*> v; ~Release() { for (DevBuf* b : v) b->release(); } } rel{ { &d_tc, &d_q, &d_len, &d_min, &d_row, &d_ev, &d_cnt } };
+	rc = upload(E, d_tc, tc.data(), tc.size()); if (rc) return rc;
+	rc = upload(E, d_q, qc.data(), qc.size()); if (rc) return rc;
+	rc = upload(E, d_len, lens, sizeof(int32_t) * nprob); if (rc) return rc;
+	rc = upload(E, d_min, min_scores, sizeof(int64_t) * nprob); if (rc) return rc;
+	const int64_t row_stride = (maxlen + 2 + 15) & ~15;
+	HIPOK(d_row.ensure((size_t)nprob * 2 * row_stride * sizeof(uint64_t)));
+	HIPOK(d_cnt.ensure(sizeof(uint32_t) * nprob));
+	// events: a first guess of one cell in six; units that need more are run again with room for every cell
+	std::vector<int> todo(nprob);
+	for (int k = 0; k < nprob; k++) todo[k] = k;
+	size_t cap = std::max<size_t>(4096, (size_t)E->m * (size_t)maxlen / 6);
+	std::vector<SimEvent> ev, sorted;
+	for (int attempt = 0; attempt < 2 && !todo.empty(); attempt++, cap = (size_t)E->m * (size_t)maxlen + 64) {
+		// bounded memory: slices of units whose event buffers fit 2 GiB
+		const size_t per_slice = std::max<size_t>(1, ((size_t)2 << 30) / (cap * sizeof(SimEvent)));
+		std::vector<int> next;
+		for (size_t s0 = 0; s0 < todo.size(); s0 += per_slice) {
+			const size_t cnt = std::min(per_slice, todo.size() - s0);
+			// the slice's units are addressed through offset pointers: unit u of the slice = problem todo[s0 + u]; the kernel
+			// indexes tcodes / unit_len / min_score / rowbuf by blockIdx, so contiguous runs of problem indices are launched together
+			size_t r0 = 0;
+			while (r0 < cnt) {
+				size_t r1 = r0 + 1;
+				while (r1 < cnt && todo[s0 + r1] == todo[s0 + r1 - 1] + 1) r1++;
+				const int first = todo[s0 + r0], nrun = (int)(r1 - r0);
+				HIPOK(d_ev.ensure((size_t)nrun * cap * sizeof(SimEvent)));
+				HIPOK(hipMemsetAsync(d_cnt.p, 0, sizeof(uint32_t) * nrun, E->st));
+				SimFwdArgs a;
+				a.tcodes = d_tc.as<uint8_t>() + (size_t)first * tstride; a.unit_len = d_len.as<int32_t>() + first; a.tstride = tstride;
+				a.qcodes = d_q.as<uint8_t>(); a.m = E->m; a.min_score = d_min.as<int64_t>() + first;
+				a.rowbuf = d_row.as<uint64_t>() + (size_t)first * 2 * row_stride; a.row_stride = row_stride;
+				a.events = d_ev.as<SimEvent>(); a.event_cap = (uint32_t)cap; a.event_count = d_cnt.as<uint32_t>();
+				hipError_t he;
+				{ TimedScope ts(E, 7); he = launch_sim_forward(a, nrun, E->st); }
+				if (he != hipSuccess) return fail(E, FASIM_E_HIP, "sim_forward launch failed: %s", hipGetErrorString(he));
+				std::vector<uint32_t> cnts((size_t)nrun);
+				HIPOK(hipMemcpyAsync(cnts.data(), d_cnt.p, sizeof(uint32_t) * nrun, hipMemcpyDeviceToHost, E->st));
+				HIPOK(hipStreamSynchronize(E->st));
+				for (int u = 0; u < nrun; u++) {
+					const int k = first + u;
+					if (cnts[(size_t)u] > cap) { next.push_back(k); continue; }
+					ev.resize(cnts[(size_t)u]);
+					if (!ev.empty()) {
+						HIPOK(hipMemcpyAsync(ev.data(), d_ev.as<SimEvent>() + (size_t)u * cap, sizeof(SimEvent) * ev.size(), hipMemcpyDeviceToHost, E->st));
+						HIPOK(hipStreamSynchronize(E->st));
+					}
+					// events arrive in (step, lane) order: within one row the columns ascend; a stable bucket pass by row gives
+					// the row-major order addnode needs
+					std::vector<uint32_t> start((size_t)E->m + 2, 0);
+					for (const SimEvent& e : ev) start[(size_t)e.i + 1]++;
+					for (size_t r = 1; r < start.size(); r++) start[r] += start[r - 1];
+					sorted.resize(ev.size());
+					for (const SimEvent& e : ev) sorted[start[(size_t)e.i]++] = e;
+					std::vector<fasim_sim_node> list;
+					sim_replay_nodes(sorted, list);
+					counts[k] = (int32_t)list.size();
+					for (size_t x = 0; x < list.size(); x++) nodes[(size_t)k * FASIM_SIM_K + x] = list[x];
+				}
+				r0 = r1;
+			}
+		}
+		todo.swap(next);
+	}
+	if (!todo.empty()) return fail(E, FASIM_E_HIP, "sim_forward: event buffer overflow after the retry");
+	drain_timed(E);
+	return FASIM_OK;
+}
+
 int fasim_pick_candidates(const int32_t* cols, int32_t n, int32_t threshold, int32_t* out_score, int32_t* out_pos,
 	int32_t cap, int32_t* count)
 {

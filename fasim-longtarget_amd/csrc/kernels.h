@@ -73,4 +73,7 @@ hipError_t launch_finish_big(const uint8_t* tcodes, const uint8_t* qcodes, const
 	const int32_t* idx_list, int32_t nlist, uint8_t* scratch, int32_t scratch_cap, AlignOutDev* out, uint32_t* cigar_pool,
 	uint32_t pool_cap, uint32_t* pool_count, hipStream_t st);
 
+// ---- sim.hip: forward sweep of classic SIM (-F), one wave per unit ---------------------------------------
+hipError_t launch_sim_forward(const SimFwdArgs& a, int32_t nunit, hipStream_t st);
+
 } // namespace fasim

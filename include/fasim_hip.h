@@ -93,6 +93,19 @@ int fasim_align_batch(fasim_engine* e, const char* windows, const int64_t* offse
  * execution order of LongTarget(): target[n] and src[n] (src is NUL-padded if letters were dropped). */
 int fasim_encode_unit(const char* seg, int32_t n, int32_t enc, char* target, char* src);
 
+/* ---- row f3 (first step): the -F path, classic SIM (sim.h:410-1143) ----------------------------- */
+/* The forward sweep of SIM() (sim.h:506-571) on the GPU: local alignment scores with start points over the whole
+ * (query x target) matrix, every cell above `min_score` fed to the K = 50 node list in row-major order (addnode,
+ * sim.h:99-148).  Returns the node list the sweep leaves, in list order: what the reference holds when its traceback
+ * loop starts (sim.h:572).  Scores are the reference's x10 values; min_score is compared unscaled, as the reference
+ * does (sim.h:567).  The remaining steps of SIM (linear-space traceback, region recomputation) are not on this path yet:
+ * `fasim -F` is still refused.  Query and targets: ACGT (other letters score as mismatches; the reference reads an
+ * uninitialised table there), at most 8191 long. */
+typedef struct fasim_sim_node { int64_t score, stari, starj, endi, endj, top, bot, left, right; } fasim_sim_node;
+#define FASIM_SIM_K 50
+int fasim_sim_forward_batch(fasim_engine* e, const char* targets, const int64_t* offsets, const int32_t* lens, int32_t nprob,
+                            const int64_t* min_scores, fasim_sim_node* nodes /* [nprob][FASIM_SIM_K] */, int32_t* counts /* [nprob] */);
+
 /* ---- the batched body of LongTarget() (Fasim-LongTarget.cpp:379-598) -------------------------- */
 /* One record per triplex that survives fastSIM()'s own filter and LongTarget()'s tail filter, in the
  * reference's order (segment, encoding, fastSIM rank).  Strings live in `pool` (NUL-terminated).   */

@@ -501,7 +501,7 @@ Alignment align(const std::string& rna, const std::string& window)
 }
 
 // ---- a12/a13: triplex construction (fastsim.h:291-414, 416-560; sim.h:72-97) ---------------------
-static float triplex_score(char c1, char c2, int para)
+float triplex_score(char c1, char c2, int para)
 {
 	if (para > 0) {
 		if (c1 == 'A' && c2 == 'T') return 3.7; else if (c1 == 'T' && c2 == 'G') return 2.8;
@@ -651,7 +651,11 @@ static void run_one_unit(const Params& p, const std::string& rna, const std::str
 	const int minscore = (int)(s1 * 0.8);
 	UnitTrace tr; UnitTrace* trp = nullptr;
 	if (traces) { tr.seg = segi; tr.enc = enc; tr.dna_start = dna_start; tr.n = (int)target.size(); tr.stage1 = s1; tr.thr = minscore; trp = &tr; }
-	fast_sim_unit(rna, target, src, dna_start, minscore, e.strand, e.para, e.rule, p, out, trp);
+	if (p.classicSim) {
+		const size_t before = out.size();
+		sim_unit(rna, target, src, dna_start, minscore, e.strand, e.para, e.rule, p, out);
+		if (trp) trp->triplexes.assign(out.begin() + (long)before, out.end());
+	} else fast_sim_unit(rna, target, src, dna_start, minscore, e.strand, e.para, e.rule, p, out, trp);
 	if (traces) traces->push_back(std::move(tr));
 }
 
@@ -678,17 +682,21 @@ void long_target(const Params& p, const std::string& rna, const std::string& dna
 	const std::vector<int> encs = enabled_encodings(p);
 	const int nseg = (int)starts.size();
 	const int lo = std::max(0, seg_first), hi = (int)std::min<long>(nseg, (long)seg_first + seg_count);
-	std::vector<std::vector<Triplex>> per_seg(nseg);
-	std::vector<std::vector<UnitTrace>> per_seg_tr(nseg);
+	// one work item per (segment, encoding) unit; results are put back into canonical order afterwards
+	const int nenc = (int)encs.size();
+	std::vector<std::vector<Triplex>> per_unit((size_t)nseg * (size_t)std::max(1, nenc));
+	std::vector<std::vector<UnitTrace>> per_unit_tr(per_unit.size());
 	std::vector<char> skip(nseg, 0);
-	std::atomic<int> next(lo);
+	for (int s = lo; s < hi; s++) skip[s] = same_seq(dna.substr(starts[s], p.cutLength)) ? 1 : 0;
+	std::atomic<long> next((long)lo * nenc);
 	auto worker = [&]() {
 		for (;;) {
-			const int s = next.fetch_add(1);
-			if (s >= hi) break;
+			const long u = next.fetch_add(1);
+			if (u >= (long)hi * nenc) break;
+			const int s = (int)(u / nenc), k = (int)(u % nenc);
+			if (skip[s]) continue;
 			const std::string seg = dna.substr(starts[s], p.cutLength);
-			if (same_seq(seg)) { skip[s] = 1; continue; }
-			for (int enc : encs) run_one_unit(p, rna, seg, s, enc, starts[s], per_seg[s], traces ? &per_seg_tr[s] : nullptr);
+			run_one_unit(p, rna, seg, s, encs[k], starts[s], per_unit[(size_t)u], traces ? &per_unit_tr[(size_t)u] : nullptr);
 		}
 	};
 	if (threads <= 1) worker();
@@ -696,8 +704,11 @@ void long_target(const Params& p, const std::string& rna, const std::string& dna
 	std::vector<Triplex> all;
 	for (int s = lo; s < hi; s++) {
 		if (skip[s] && skipped) skipped->push_back(s);
-		for (auto& t : per_seg[s]) all.push_back(t);
-		if (traces) for (auto& t : per_seg_tr[s]) traces->push_back(std::move(t));
+		for (int k = 0; k < nenc; k++) {
+			const size_t u = (size_t)s * nenc + k;
+			for (auto& t : per_unit[u]) all.push_back(t);
+			if (traces) for (auto& t : per_unit_tr[u]) traces->push_back(std::move(t));
+		}
 	}
 	for (const Triplex& a : all)
 		if (a.score >= p.scoreMin && a.identity >= p.minIdentity && a.tri_score >= p.minStability && a.nt >= p.cLength) out.push_back(a);
@@ -894,6 +905,17 @@ int fo_align(const char* rna, int m, const char* window, int n, int* out5, uint3
 	if ((int)a.cigar.size() > cap) return -1;
 	for (size_t i = 0; i < a.cigar.size(); i++) cigar[i] = a.cigar[i];
 	return (int)a.cigar.size();
+}
+int fo_sim_forward_nodes(const char* rna, int m, const char* target, int n, long min_score, long* out, int cap)
+{
+	std::vector<fo::SimNode> nodes;
+	fo::sim_forward_nodes(std::string(rna, m), std::string(target, n), min_score, nodes);
+	for (int k = 0; k < (int)nodes.size() && k < cap; k++) {
+		const fo::SimNode& v = nodes[k];
+		const long f[9] = { v.score, v.stari, v.starj, v.endi, v.endj, v.top, v.bot, v.left, v.right };
+		for (int x = 0; x < 9; x++) out[9 * k + x] = f[x];
+	}
+	return (int)nodes.size();
 }
 void fo_encode_unit(const char* seg, int n, int enc, char* target, char* src)
 {

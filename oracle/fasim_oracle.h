@@ -59,6 +59,7 @@ struct Params {   // Fasim-LongTarget.cpp:284-303 defaults
 	int ntMin = 20, ntMax = 100000;
 	float scoreMin = 0.0f, minIdentity = 60.0f, minStability = 1.0f;
 	int penaltyT = -1000, penaltyC = 0, cDistance = 15, cLength = 50;
+	bool classicSim = false;   // -F: doFastSim = false (Fasim-LongTarget.cpp:360-362): SIM() instead of fastSIM()
 };
 struct TryRecord { int it, L; Alignment a; };
 struct UnitTrace {      // everything the probe prints for one unit
@@ -71,6 +72,15 @@ struct UnitTrace {      // everything the probe prints for one unit
 void fast_sim_unit(const std::string& rna, const std::string& target, const std::string& src,
 	long dna_start, int min_score, int strand, int para, int rule, const Params& p,
 	std::vector<Triplex>& out, UnitTrace* trace);
+
+// ---- row f3: the -F path, classic SIM (sim.h:99-1143; oracle/fasim_sim_oracle.cpp) -----------------
+float triplex_score(char c1, char c2, int para);                       // sim.h:72-97
+struct SimNode { long score, stari, starj, endi, endj, top, bot, left, right; };   // vertex (sim.h:47-58)
+// SIM() for one unit: appends the unit's triplexes (nt within [ntMin, ntMax]) in the reference's order
+void sim_unit(const std::string& rna, const std::string& target, const std::string& src, long dna_start, long min_score,
+	int strand, int para, int rule, const Params& p, std::vector<Triplex>& out);
+// only the first sweep of SIM() (sim.h:506-571): the node list it leaves (checker of the HIP forward pass)
+void sim_forward_nodes(const std::string& rna, const std::string& target, long min_score, std::vector<SimNode>& nodes);
 
 // ---- whole scan: LongTarget() (Fasim-LongTarget.cpp:379-598) --------------------------------
 // Units are enumerated in canonical (segment, encoding) order; `traces` (optional) gets one entry
@@ -101,6 +111,8 @@ int  fo_pick_candidates(const int* cols, int n, int thr, int* out_score, int* ou
 // out[0..4] = score, ref_begin, ref_end, query_begin, query_end; returns cigar length (<= cap) or -1
 int  fo_align(const char* rna, int m, const char* window, int n, int* out5, uint32_t* cigar, int cap);
 void fo_encode_unit(const char* seg, int n, int enc, char* target, char* src);
+// first sweep of SIM(): out[9 * k ..] = score, stari, starj, endi, endj, top, bot, left, right of node k; returns the node count
+int  fo_sim_forward_nodes(const char* rna, int m, const char* target, int n, long min_score, long* out, int cap);
 }
 
 #endif

@@ -13,6 +13,7 @@
 //   Aligner::preAlign (ssw_cpp.cpp:388)   -> candidates
 //   Aligner::Align    (ssw_cpp.cpp:599)   -> window alignments
 //   fastSIM           (fastsim.h:158)     -> per-unit triplex list
+//   SIM               (sim.h:410)         -> per-unit triplex list of the -F (classic SIM) path  [simscan]
 // and re-states only the unit enumeration of LongTarget() (Fasim-LongTarget.cpp:395-586),
 // which cannot be linked because it lives in the file that defines main().
 //
@@ -168,9 +169,35 @@ static void run_unit(const std::string& rna, const std::string& seq1, int seg, i
 	}
 }
 
+// -F path: the reference's SIM() for one unit (Fasim-LongTarget.cpp:420-426 and the other seven call sites)
+static void run_unit_sim(const std::string& rna, const std::string& seq1, int seg, int enc, long dnaStartPos, const unit_desc& u, struct para& pl)
+{
+	std::string seq2, src;
+	if (u.Para > 0 && u.strand == 0) { seq2 = transferString(seq1, 0, 1, u.rule); src = seq1; }
+	else if (u.Para > 0 && u.strand == 1) { seq2 = transferString(seq1, 1, 1, u.rule); reverseSeq(seq2); src = seq1; complement(src); reverseSeq(src); }
+	else if (u.Para < 0 && u.strand == 1) { seq2 = transferString(seq1, 1, -1, u.rule); src = seq1; complement(src); }
+	else { seq2 = transferString(seq1, 0, -1, u.rule); reverseSeq(seq2); src = seq1; reverseSeq(src); }
+	std::string rnac = rna;
+	int s1 = calc_score_once(rnac, seq2, (int)dnaStartPos, pl.rule);
+	int minscore = s1 * 0.8;
+	std::vector<struct triplex> tl;
+	std::string a = rna, b = seq2, c = src;
+	SIM(a, b, c, dnaStartPos, minscore, 5, -4, -12, -4, tl, u.strand, u.Para, u.rule, pl.ntMin, pl.ntMax, pl.penaltyT, pl.penaltyC);
+	// V seg enc dnaStartPos strand Para rule n stage1 thr ntriplex
+	printf("V %d %d %ld %d %d %d %d %d %d %d\n", seg, enc, dnaStartPos, u.strand, u.Para, u.rule, (int)seq2.size(), s1, minscore, (int)tl.size());
+	for (size_t i = 0; i < tl.size(); i++) {
+		const struct triplex& t = tl[i];
+		printf("X %d %d %d %d %d %d %d %d %d %08x %08x %s %s\n", t.stari, t.endi, t.starj, t.endj, t.strand,
+			t.reverse, t.rule, t.nt, (int)t.score, fbits(t.identity), fbits(t.tri_score),
+			t.stri_align.c_str(), t.strj_align.c_str());
+	}
+	fflush(stdout);
+}
+
 static int cmd_scan(int argc, char** argv)
 {
-	if (argc < 4) { fprintf(stderr, "usage: scan rna.fa dna.fa [-r R] [-t T] [-detail 0|1] [-segfirst a] [-segcount n] [flags as fasim]\n"); return 2; }
+	if (argc < 4) { fprintf(stderr, "usage: scan|simscan rna.fa dna.fa [-r R] [-t T] [-detail 0|1] [-segfirst a] [-segcount n] [flags as fasim]\n"); return 2; }
+	const bool classic = !strcmp(argv[1], "simscan");      // -F: SIM() instead of fastSIM()
 	std::string rh, rna, dh, dna;
 	if (!read_fasta(argv[2], rh, rna) || !read_fasta(argv[3], dh, dna)) { fprintf(stderr, "cannot read input\n"); return 2; }
 	struct para pl;
@@ -208,16 +235,16 @@ static int cmd_scan(int argc, char** argv)
 			for (int j = 1; j <= 6; j++) {
 				unit_desc a = { 0, 1, j }, b = { 1, 1, j };
 				bool on = (pl.rule == 0) || (pl.rule == j);
-				if (on) run_unit(rna, seq1, s, enc, starts[s], a, pl, detail); enc++;
-				if (on) run_unit(rna, seq1, s, enc, starts[s], b, pl, detail); enc++;
+				if (on) { if (classic) run_unit_sim(rna, seq1, s, enc, starts[s], a, pl); else run_unit(rna, seq1, s, enc, starts[s], a, pl, detail); } enc++;
+				if (on) { if (classic) run_unit_sim(rna, seq1, s, enc, starts[s], b, pl); else run_unit(rna, seq1, s, enc, starts[s], b, pl, detail); } enc++;
 			}
 		} else enc = 12;
 		if (pl.strand <= 0) {
 			for (int j = 1; j <= 18; j++) {
 				unit_desc a = { 1, -1, j }, b = { 0, -1, j };
 				bool on = (pl.rule == 0) || (pl.rule == j);
-				if (on) run_unit(rna, seq1, s, enc, starts[s], a, pl, detail); enc++;
-				if (on) run_unit(rna, seq1, s, enc, starts[s], b, pl, detail); enc++;
+				if (on) { if (classic) run_unit_sim(rna, seq1, s, enc, starts[s], a, pl); else run_unit(rna, seq1, s, enc, starts[s], a, pl, detail); } enc++;
+				if (on) { if (classic) run_unit_sim(rna, seq1, s, enc, starts[s], b, pl); else run_unit(rna, seq1, s, enc, starts[s], b, pl, detail); } enc++;
 			}
 		}
 	}
@@ -270,7 +297,7 @@ static int cmd_batch()
 
 int main(int argc, char** argv)
 {
-	if (argc >= 2 && !strcmp(argv[1], "scan")) return cmd_scan(argc, argv);
+	if (argc >= 2 && (!strcmp(argv[1], "scan") || !strcmp(argv[1], "simscan"))) return cmd_scan(argc, argv);
 	if (argc >= 2 && !strcmp(argv[1], "batch")) return cmd_batch();
 	fprintf(stderr, "usage: ref_probe scan rna.fa dna.fa [opts] | ref_probe batch < requests\n");
 	return 2;

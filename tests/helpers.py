@@ -36,6 +36,9 @@ class Oracle:
         L.fo_align.restype = ctypes.c_int
         L.fo_align.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
                                ctypes.POINTER(ctypes.c_uint32), ctypes.c_int]
+        L.fo_sim_forward_nodes.restype = ctypes.c_int
+        L.fo_sim_forward_nodes.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_long,
+                                           ctypes.POINTER(ctypes.c_long), ctypes.c_int]
         L.fo_encode_unit.restype = None
         L.fo_encode_unit.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p]
 
@@ -61,6 +64,12 @@ class Oracle:
         k = self.lib.fo_align(q, len(q), w, len(w), out5, cig, 4096)
         assert k >= 0
         return tuple(out5), cigar_to_string(cig[:k])
+
+    def sim_forward_nodes(self, q: bytes, t: bytes, min_score: int):
+        """node list after the first sweep of SIM() (oracle/fasim_sim_oracle.cpp), as 9-tuples in list order"""
+        out = (ctypes.c_long * (9 * 50))()
+        k = self.lib.fo_sim_forward_nodes(q, len(q), t, len(t), min_score, out, 50)
+        return [tuple(out[9 * x + y] for y in range(9)) for x in range(k)]
 
     def encode_unit(self, seg: bytes, enc: int):
         t = ctypes.create_string_buffer(len(seg))

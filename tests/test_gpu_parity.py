@@ -625,3 +625,29 @@ def test_genome_like_1mb_long_queries(mod, golden_dir, name, rna_src, kw):
     print(f"{name}: {st['units']} units, {st['candidates']} candidates, hazard {st['hazard_units']}, overflow {st['stage2_overflow_units']}, "
           f"rev_exact {st['rev_exact']}, replays {st['exact_replays']}, word reruns {st['align_word_reruns']}, {res.count} records, {st['t_total_s']:.2f} s")
     e.close()
+
+
+# ---- row f3: forward sweep of classic SIM (-F) ---------------------------------------------------------------------------
+def test_sim_forward_sweep_node_lists(mod, engine, h19, golden_dir, oracle_build):
+    """k_sim_forward + the host replay of addnode: the K = 50 node list SIM() holds after its first sweep (sim.h:506-571), for
+    demo units of all four strand / direction classes and a planted 3 kb target, against the oracle's restatement (which is
+    pinned end to end by the reference's own -F outputs, tests/test_oracle_golden.py)."""
+    o = helpers.Oracle(oracle_build)
+    _, dna = synth.read_fasta(os.path.join(golden_dir, "testDNA.fa"))
+    engine.set_query(h19)
+    targets, mins = [], []
+    for enc in (0, 1, 12, 13, 30, 47):
+        t, _ = o.encode_unit(dna, enc)
+        targets.append(t)
+        mins.append(int(o.stage1_max(h19, t) * 0.8))
+    small = synth.planted_dna(3000, 77, h19, every=400)
+    t, _ = o.encode_unit(small, 5)
+    targets.append(t)
+    mins.append(int(o.stage1_max(h19, t) * 0.8))
+    targets.append(b"ACGT" * 5)          # shorter than one strip of rows; nothing above the threshold
+    mins.append(100000)
+    got = engine.sim_forward(targets, mins)
+    for k, (t, ms) in enumerate(zip(targets, mins)):
+        exp = o.sim_forward_nodes(h19, t, ms)
+        assert got[k] == exp, (k, len(got[k]), len(exp), got[k][:2], exp[:2])
+    assert len(got[0]) == 50 and got[-1] == []

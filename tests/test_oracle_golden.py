@@ -155,3 +155,29 @@ def test_untidy_input(oracle_build, golden_dir):
     assert meta["skipped"], "fixture must contain a skipped all-N segment"
     out = helpers.oracle_cli(oracle_build, "tfosorted", rna, dna, "-lg", "30", "-threads", "8")
     assert out == open(os.path.join(golden_dir, "messy.TFOsorted"), "rb").read()
+
+
+# ---- row f3: the -F path (classic SIM, sim.h:410-1143) ------------------------------------------------------------------
+def test_classic_sim_demo_units_identical(oracle_build, golden_dir):
+    """oracle `simscan` (oracle/fasim_sim_oracle.cpp) against the reference's own SIM() for all 48 units of the demo:
+    stage-1 score, threshold and every triplex (coordinates, nt, score, identity / stability as float bits, both strings)."""
+    out = helpers.oracle_cli(oracle_build, "simscan", os.path.join(golden_dir, "H19.fa"), os.path.join(golden_dir, "testDNA.fa"), "-threads", "8")
+    gold = helpers.gunzip(os.path.join(golden_dir, "demoF.simscan.gz"))
+    assert out == gold
+    assert gold.count(b"\nX ") > 500
+
+
+def test_classic_sim_planted12k_identical(oracle_build, golden_dir, tmp_path):
+    _, rna = synth.read_fasta(os.path.join(golden_dir, "H19.fa"))
+    dna = _write(tmp_path, "simF12k.fa", b">syn|chrF|1-12000\n" + synth.planted_dna(12000, 909, rna, every=700) + b"\n")
+    out = helpers.oracle_cli(oracle_build, "simscan", os.path.join(golden_dir, "H19.fa"), dna, "-threads", "8")
+    assert out == helpers.gunzip(os.path.join(golden_dir, "simF12k.simscan.gz"))
+
+
+def test_classic_sim_cli_files_identical(oracle_build, golden_dir):
+    """`fasim_ref -F -lg 40` on the demo: -TFOsorted and both -TFOclass files from the oracle's -F path."""
+    rna, dna = os.path.join(golden_dir, "H19.fa"), os.path.join(golden_dir, "testDNA.fa")
+    out = helpers.oracle_cli(oracle_build, "tfosorted", rna, dna, "-lg", "40", "-F", "1", "-threads", "8")
+    assert out == open(os.path.join(golden_dir, "demoF_lg40.TFOsorted"), "rb").read()
+    out = helpers.oracle_cli(oracle_build, "tfoclass", rna, dna, "-lg", "40", "-F", "1", "-level", "1", "-threads", "8")
+    assert out == open(os.path.join(golden_dir, "demoF_lg40.TFOclass1"), "rb").read()
