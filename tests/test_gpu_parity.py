@@ -651,3 +651,44 @@ def test_sim_forward_sweep_node_lists(mod, engine, h19, golden_dir, oracle_build
         exp = o.sim_forward_nodes(h19, t, ms)
         assert got[k] == exp, (k, len(got[k]), len(exp), got[k][:2], exp[:2])
     assert len(got[0]) == 50 and got[-1] == []
+
+
+# ---- BASELINE config 2 at its full size ----------------------------------------------------------------------------------
+def test_full_size_50mb_reference_validated_digest_and_sharding_invariance(mod, h19):
+    """The bench's whole 50 Mb record (splitmix64 seed 12345), H19, default parameters.
+    (1) Cut into the same 13 slices at segment boundaries as tests/parity/parity_sharded.py, every slice scanned and its three
+    output files hashed in that script's order: the digest must be the one recorded in profiles/r01_parity_big_vs_reference.log
+    for the run in which all 39 files were byte-identical to the compiled reference on the GPU box (260 649 triplex lines).
+    (2) Size-independent property: the whole record scanned as 3 contiguous segment shards and merged natively equals the
+    unsharded scan, record for record."""
+    import hashlib
+    total, nsl = 50_000_000, 13
+    dna = mod.synth_dna(total, 12345)
+    p = mod.default_params()
+    e = mod.Engine(0)
+    e.set_query(h19)
+    nseg = (total - 5000) // 4900 + 1
+    per = (nseg + nsl - 1) // nsl
+    h = hashlib.sha256()
+    lines = 0
+    for k in range(nsl):
+        a, b = k * per, min(nseg, (k + 1) * per)
+        if a >= b:
+            break
+        lo, hi = a * 4900, min(total, (b - 1) * 4900 + 5000)
+        res = e.scan(dna[lo:hi], p)
+        tfo, c1, c2 = mod.tail_outputs(res, "chrB", lo + 1, hi - lo, "H19", p)
+        for text in (c1, c2, tfo):                      # file-name order: ...-TFOclass1-15-50, ...-TFOclass2-15-50, ...-TFOsorted
+            h.update(text)
+        lines += tfo.count(b"\n") - 1
+    assert lines == 260649
+    assert h.hexdigest()[:16] == "3868117966c38486"
+    e.load_dna(dna)
+    whole = e.scan(None, p)
+    assert whole.count == 265583 and whole.stats["units"] == 489840
+    nall = mod.segment_count(total, p)
+    cuts = [0, nall // 3, 2 * nall // 3, nall]
+    parts = [e.scan(None, p, cuts[i], cuts[i + 1] - cuts[i]) for i in range(3)]
+    merged = mod.merge_results(parts)
+    assert merged.count == whole.count and merged.recs == whole.recs and merged.pool == whole.pool
+    e.close()
