@@ -37,7 +37,7 @@ class Params(C.Structure):
     _fields_ = [("rule", C.c_int32), ("cutLength", C.c_int32), ("strand", C.c_int32), ("overlapLength", C.c_int32),
                 ("ntMin", C.c_int32), ("ntMax", C.c_int32), ("scoreMin", C.c_float), ("minIdentity", C.c_float),
                 ("minStability", C.c_float), ("penaltyT", C.c_int32), ("penaltyC", C.c_int32), ("cDistance", C.c_int32),
-                ("cLength", C.c_int32)]
+                ("cLength", C.c_int32), ("classicSim", C.c_int32)]
 
 
 class Alignment(C.Structure):
@@ -84,7 +84,7 @@ class _Result(C.Structure):
 
 EXPORTS = ["fasim_params_default", "fasim_engine_create", "fasim_engine_destroy", "fasim_last_error", "fasim_set_option", "fasim_set_query",
            "fasim_calc_score_once", "fasim_ssw_pre_align", "fasim_ssw_colmax_word", "fasim_pick_candidates", "fasim_ssw_align", "fasim_pre_align_batch",
-           "fasim_align_batch", "fasim_encode_unit", "fasim_sim_forward_batch", "fasim_scan", "fasim_scan_queries", "fasim_merge_results", "fasim_rebase_offsets", "fasim_load_dna", "fasim_result_free", "fasim_segment_count",
+           "fasim_align_batch", "fasim_encode_unit", "fasim_sim_forward_batch", "fasim_sim_finish_unit", "fasim_scan", "fasim_scan_queries", "fasim_merge_results", "fasim_rebase_offsets", "fasim_load_dna", "fasim_result_free", "fasim_segment_count",
            "fasim_tfosorted", "fasim_tfoclass", "fasim_tfosorted_ex", "fasim_tfoclass_ex", "fasim_tail_outputs", "fasim_upper_case", "fasim_free",
            "fasim_synth_dna",
            # the reference's own ssw.h ABI (include/ssw.h)
@@ -121,6 +121,8 @@ def lib():
     L.fasim_align_batch.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int32,
                                     C.POINTER(Alignment)]
     L.fasim_encode_unit.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_char_p, C.c_char_p]
+    L.fasim_sim_finish_unit.argtypes = [C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.POINTER(Params),
+                                        C.POINTER(SimNode), C.c_int32, C.POINTER(C.POINTER(_Result))]
     L.fasim_sim_forward_batch.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int32,
                                           C.POINTER(C.c_int64), C.POINTER(SimNode), C.POINTER(C.c_int32)]
     L.fasim_scan.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(Params),
@@ -457,6 +459,21 @@ class Engine:
                                                seg_count, C.byref(p), outs))
         self.m = len(rnas[-1])
         return [ScanResult(stats=self._stats_dict(outs[k].contents.stats), _native=outs[k]) for k in range(n)]
+
+
+def sim_finish_unit(rna: bytes, seg: bytes, enc: int, dna_start: int, min_score: int, nodes, params: Params | None = None) -> "ScanResult":
+    """Host half of the -F path for one unit (fasim_sim_finish_unit): `nodes` = 9-tuples of the forward sweep's node list."""
+    L = lib()
+    p = params or default_params()
+    arr = (SimNode * max(1, len(nodes)))()
+    for k, t in enumerate(nodes):
+        for (name, _), v in zip(SimNode._fields_, t):
+            setattr(arr[k], name, v)
+    res = C.POINTER(_Result)()
+    rc = L.fasim_sim_finish_unit(rna, len(rna), seg, len(seg), enc, dna_start, min_score, C.byref(p), arr, len(nodes), C.byref(res))
+    if rc != 0:
+        raise FasimError(f"fasim_sim_finish_unit failed ({rc}): {L.fasim_last_error(None).decode()}")
+    return ScanResult(stats={}, _native=res)
 
 
 def pick_candidates(cols, threshold):

@@ -74,7 +74,8 @@ struct fasim_engine {
 	ScoreLut lut1, lut2;
 	DevBuf q1, q2, enc_lut, counter, dna, seg_start, seg_len, enc_ids, tcodes, colmax, probs, max_out, unit_len,
 		stage1, hits, hits_total, hit_off, hit_cnt, thr, ends, bprobs, bout, scratch, colmax16, unit_ids, flags, stage1_in, hits2,
-		fprobs, ftasks, fstream, fout, aout, cigpool, cigcount, forder, scratch2, boundary, fboundary, unit_hz;
+		fprobs, ftasks, fstream, fout, aout, cigpool, cigcount, forder, scratch2, boundary, fboundary, unit_hz,
+		qsim, sim_min, sim_row, sim_ev, sim_cnt;      // -F: query codes of the SIM alphabet, thresholds, strip row buffer, events, counters
 	bool align_v1 = false;        // FASIM_ALIGN_V1=1: force the stripe-faithful kernels for stage 3
 	std::vector<fasim_engine*> workers;   // extra engines on the same device: batches in flight concurrently
 	// Gate for the two GPU-filling kernels (k_scan, k_align_fwd).  Without it the workers fall into lock step: all of them
@@ -118,6 +119,8 @@ int fail(fasim_engine* e, int code, const char* fmt, ...)
 
 // stage-2/3 alphabet (ssw_cpp.cpp:13-26): A,a,U,u -> 0 ; C,c -> 1 ; G,g -> 2 ; T,t -> 3 ; else 4
 inline uint8_t code2(char c) { switch (c) { case 'A': case 'a': case 'U': case 'u': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; } }
+// SIM (-F) alphabet: the score table of sim.h:464-468 knows ACGT only; every other letter is a mismatch with everything
+inline uint8_t sim_code(char c) { switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return 4; } }
 // stage-1 alphabet (stats.h:201-228, 306-334): U == T, everything outside ACGTU is N
 inline uint8_t code1(char c) { switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': case 'U': case 'u': return 3; default: return 4; } }
 
@@ -831,13 +834,15 @@ int need_query(fasim_engine* E)
 // =====================================================================================================
 // C-ABI
 // =====================================================================================================
+static int pack_result(fasim_engine* E, std::vector<HostTriplex>& all, const fasim_scan_stats& st, fasim_result** out);
+
 extern "C" {
 
 void fasim_params_default(fasim_params* p)
 {
 	p->rule = 0; p->cutLength = 5000; p->strand = 0; p->overlapLength = 100; p->ntMin = 20; p->ntMax = 100000;
 	p->scoreMin = 0.0f; p->minIdentity = 60.0f; p->minStability = 1.0f; p->penaltyT = -1000; p->penaltyC = 0;
-	p->cDistance = 15; p->cLength = 50;
+	p->cDistance = 15; p->cLength = 50; p->classicSim = 0;
 }
 
 const char* fasim_last_error(const fasim_engine* e) { return e ? e->err.c_str() : g_last_error.c_str(); }
@@ -898,7 +903,8 @@ void fasim_engine_destroy(fasim_engine* e)
 	DevBuf* bufs[] = { &e->q1, &e->q2, &e->enc_lut, &e->counter, &e->dna, &e->seg_start, &e->seg_len, &e->enc_ids, &e->tcodes,
 		&e->colmax, &e->probs, &e->max_out, &e->unit_len, &e->stage1, &e->hits, &e->hits_total, &e->hit_off, &e->hit_cnt, &e->thr,
 		&e->ends, &e->bprobs, &e->bout, &e->scratch, &e->dna_res, &e->colmax16, &e->unit_ids, &e->flags, &e->stage1_in, &e->hits2,
-		&e->fprobs, &e->ftasks, &e->fstream, &e->fout, &e->aout, &e->cigpool, &e->cigcount, &e->forder, &e->scratch2, &e->boundary, &e->fboundary, &e->unit_hz };
+		&e->fprobs, &e->ftasks, &e->fstream, &e->fout, &e->aout, &e->cigpool, &e->cigcount, &e->forder, &e->scratch2, &e->boundary, &e->fboundary, &e->unit_hz,
+		&e->qsim, &e->sim_min, &e->sim_row, &e->sim_ev, &e->sim_cnt };
 	for (auto& t : e->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
 	for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
 	for (DevBuf* b : bufs) b->release();
@@ -933,8 +939,11 @@ int fasim_set_query(fasim_engine* E, const char* rna, int32_t len)
 		const char c = rna[i];
 		if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'a' || c == 'c' || c == 'g' || c == 't')) E->query_acgt = false;
 	}
+	std::vector<uint8_t> cs(len);
+	for (int i = 0; i < len; i++) cs[i] = sim_code(rna[i]);
 	int rc = upload(E, E->q1, c1.data(), len);
 	if (!rc) rc = upload(E, E->q2, c2.data(), len);
+	if (!rc) rc = upload(E, E->qsim, cs.data(), len);
 	if (rc) return rc;
 	HIPOK(hipStreamSynchronize(E->st));
 	return FASIM_OK;
@@ -1036,89 +1045,122 @@ static void sim_replay_nodes(const std::vector<SimEvent>& ev, std::vector<fasim_
 	}
 }
 
+// Forward sweep + node-list replay for units [first, first + nrun) of a resident code buffer.  min_scores[u] belongs to unit
+// first + u.  lists[u] receives the node list.  Units are processed in slices whose event buffers fit ~2 GiB; a unit whose
+// events overflow the first guess (one cell in six) is run again with room for every cell.  The replay (order dependent,
+// ~10^6 events per 5 kb unit) runs on `threads` host threads, one unit each.
+static int sim_forward_units(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, const int32_t* unit_len_dev, const int32_t* unit_len_host,
+	int first, int nrun, const int64_t* min_scores, int threads, std::vector<std::vector<fasim_sim_node>>& lists)
+{
+	lists.assign((size_t)nrun, std::vector<fasim_sim_node>());
+	if (nrun <= 0) return FASIM_OK;
+	int maxlen = 1;
+	for (int u = 0; u < nrun; u++) maxlen = std::max(maxlen, unit_len_host[first + u]);
+	if (E->m > 8191 || maxlen > 8191) return fail(E, FASIM_E_UNSUPPORTED, "the SIM forward sweep holds start points in 13 bits: query %d / target %d nt is too long", E->m, maxlen);
+	const int64_t row_stride = (maxlen + 2 + 15) & ~15;
+	DevBuf& d_min = E->sim_min; DevBuf& d_row = E->sim_row; DevBuf& d_ev = E->sim_ev; DevBuf& d_cnt = E->sim_cnt;
+	int rc = upload(E, d_min, min_scores, sizeof(int64_t) * nrun); if (rc) return rc;
+	std::vector<int> todo((size_t)nrun);
+	for (int u = 0; u < nrun; u++) todo[(size_t)u] = u;
+	size_t cap = std::max<size_t>(4096, (size_t)E->m * (size_t)maxlen / 6);
+	for (int attempt = 0; attempt < 2 && !todo.empty(); attempt++, cap = (size_t)E->m * (size_t)maxlen + 64) {
+		const size_t per_slice = std::max<size_t>(1, std::min<size_t>(256, ((size_t)2 << 30) / (cap * sizeof(SimEvent))));
+		std::vector<int> next;
+		size_t r0 = 0;
+		while (r0 < todo.size()) {
+			// a launch covers a contiguous run of units (the kernel indexes everything by blockIdx)
+			size_t r1 = r0 + 1;
+			while (r1 < todo.size() && r1 - r0 < per_slice && todo[r1] == todo[r1 - 1] + 1) r1++;
+			const int u0 = todo[r0], cnt = (int)(r1 - r0);
+			HIPOK(d_ev.ensure((size_t)cnt * cap * sizeof(SimEvent)));
+			HIPOK(d_row.ensure((size_t)cnt * 2 * row_stride * sizeof(uint64_t)));
+			HIPOK(d_cnt.ensure(sizeof(uint32_t) * cnt));
+			HIPOK(hipMemsetAsync(d_cnt.p, 0, sizeof(uint32_t) * cnt, E->st));
+			SimFwdArgs a;
+			a.tcodes = tcodes_dev + (size_t)(first + u0) * tstride; a.unit_len = unit_len_dev + first + u0; a.tstride = tstride;
+			a.qcodes = E->qsim.as<uint8_t>(); a.m = E->m; a.min_score = d_min.as<int64_t>() + u0;
+			a.rowbuf = d_row.as<uint64_t>(); a.row_stride = row_stride;
+			a.events = d_ev.as<SimEvent>(); a.event_cap = (uint32_t)cap; a.event_count = d_cnt.as<uint32_t>();
+			hipError_t he;
+			{ TimedScope ts(E, 7); he = launch_sim_forward(a, cnt, E->st); }
+			if (he != hipSuccess) return fail(E, FASIM_E_HIP, "sim_forward launch failed: %s", hipGetErrorString(he));
+			std::vector<uint32_t> cnts((size_t)cnt);
+			HIPOK(hipMemcpyAsync(cnts.data(), d_cnt.p, sizeof(uint32_t) * cnt, hipMemcpyDeviceToHost, E->st));
+			HIPOK(hipStreamSynchronize(E->st));
+			std::vector<std::vector<SimEvent>> evs((size_t)cnt);
+			for (int k = 0; k < cnt; k++) {
+				if (cnts[(size_t)k] > cap) { next.push_back(u0 + k); continue; }
+				evs[(size_t)k].resize(cnts[(size_t)k]);
+				if (cnts[(size_t)k]) HIPOK(hipMemcpyAsync(evs[(size_t)k].data(), d_ev.as<SimEvent>() + (size_t)k * cap, sizeof(SimEvent) * cnts[(size_t)k], hipMemcpyDeviceToHost, E->st));
+			}
+			HIPOK(hipStreamSynchronize(E->st));
+			std::atomic<int> nextk(0);
+			auto work = [&]() {
+				std::vector<SimEvent> sorted; std::vector<uint32_t> start;
+				for (;;) {
+					const int k = nextk.fetch_add(1);
+					if (k >= cnt) break;
+					if (cnts[(size_t)k] > cap) continue;
+					const std::vector<SimEvent>& ev = evs[(size_t)k];
+					// events arrive in (step, lane) order: within one row the columns ascend; a stable bucket pass by row gives
+					// the row-major order addnode needs
+					start.assign((size_t)E->m + 2, 0);
+					for (const SimEvent& e : ev) start[(size_t)e.i + 1]++;
+					for (size_t r = 1; r < start.size(); r++) start[r] += start[r - 1];
+					sorted.resize(ev.size());
+					for (const SimEvent& e : ev) sorted[start[(size_t)e.i]++] = e;
+					sim_replay_nodes(sorted, lists[(size_t)(u0 + k)]);
+				}
+			};
+			const int nt = std::max(1, std::min(threads, cnt));
+			if (nt == 1) work();
+			else { std::vector<std::thread> th; for (int t = 0; t < nt; t++) th.emplace_back(work); for (auto& t : th) t.join(); }
+			r0 = r1;
+		}
+		todo.swap(next);
+	}
+	if (!todo.empty()) return fail(E, FASIM_E_HIP, "sim_forward: event buffer overflow after the retry");
+	return FASIM_OK;
+}
+
+int fasim_sim_finish_unit(const char* rna, int32_t m, const char* seg, int32_t n, int32_t enc, int64_t dna_start, int64_t min_score,
+	const fasim_params* p, const fasim_sim_node* nodes, int32_t nnodes, fasim_result** out)
+{
+	if (!rna || m <= 0 || !seg || n <= 0 || enc < 0 || enc >= 48 || !p || (nnodes > 0 && !nodes) || nnodes < 0 || nnodes > FASIM_SIM_K || !out)
+		return fail(nullptr, FASIM_E_ARG, "bad arguments");
+	std::string target, src;
+	encode_unit_host(seg, n, enc, target, src);
+	std::vector<fasim_sim_node> list(nodes, nodes + nnodes);
+	std::vector<HostTriplex> recs;
+	sim_finish_unit(std::string(rna, rna + m), target, src, (long)dna_start, (long)min_score, enc, *p, list, recs);
+	for (HostTriplex& t : recs) t.enc = enc;
+	fasim_scan_stats st; memset(&st, 0, sizeof st);
+	return pack_result(nullptr, recs, st, out);
+}
+
 int fasim_sim_forward_batch(fasim_engine* E, const char* targets, const int64_t* offsets, const int32_t* lens, int32_t nprob,
 	const int64_t* min_scores, fasim_sim_node* nodes, int32_t* counts)
 {
 	int rc = need_query(E); if (rc) return rc;
 	if (!targets || !offsets || !lens || !min_scores || !nodes || !counts || nprob <= 0) return fail(E, FASIM_E_ARG, "bad arguments");
-	if (E->m > 8191) return fail(E, FASIM_E_UNSUPPORTED, "the SIM forward sweep holds start points in 13 bits: query of %d nt is too long", E->m);
 	HIPOK(hipSetDevice(E->device));
-	auto code = [](char c) -> uint8_t { switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return 4; } };
 	int maxlen = 1;
 	for (int k = 0; k < nprob; k++) {
-		if (lens[k] <= 0 || lens[k] > 8191) return fail(E, FASIM_E_UNSUPPORTED, "target %d: length %d outside 1..8191", k, lens[k]);
+		if (lens[k] <= 0) return fail(E, FASIM_E_ARG, "empty target %d", k);
 		maxlen = std::max(maxlen, lens[k]);
 	}
 	const int tstride = (maxlen + 15) & ~15;
-	std::vector<uint8_t> tc((size_t)nprob * tstride, 4), qc((size_t)E->m);
-	for (int k = 0; k < nprob; k++) for (int c = 0; c < lens[k]; c++) tc[(size_t)k * tstride + c] = code(targets[offsets[k] + c]);
-	for (int i = 0; i < E->m; i++) qc[(size_t)i] = code(E->rna[(size_t)i]);
-	DevBuf d_tc, d_q, d_len, d_min, d_row, d_ev, d_cnt;
-	struct Release { std::vector<DevBuf*> v; ~Release() { for (DevBuf* b : v) b->release(); } } rel{ { &d_tc, &d_q, &d_len, &d_min, &d_row, &d_ev, &d_cnt } };
-	rc = upload(E, d_tc, tc.data(), tc.size()); if (rc) return rc;
-	rc = upload(E, d_q, qc.data(), qc.size()); if (rc) return rc;
-	rc = upload(E, d_len, lens, sizeof(int32_t) * nprob); if (rc) return rc;
-	rc = upload(E, d_min, min_scores, sizeof(int64_t) * nprob); if (rc) return rc;
-	const int64_t row_stride = (maxlen + 2 + 15) & ~15;
-	HIPOK(d_row.ensure((size_t)nprob * 2 * row_stride * sizeof(uint64_t)));
-	HIPOK(d_cnt.ensure(sizeof(uint32_t) * nprob));
-	// events: a first guess of one cell in six; units that need more are run again with room for every cell
-	std::vector<int> todo(nprob);
-	for (int k = 0; k < nprob; k++) todo[k] = k;
-	size_t cap = std::max<size_t>(4096, (size_t)E->m * (size_t)maxlen / 6);
-	std::vector<SimEvent> ev, sorted;
-	for (int attempt = 0; attempt < 2 && !todo.empty(); attempt++, cap = (size_t)E->m * (size_t)maxlen + 64) {
-		// bounded memory: slices of units whose event buffers fit 2 GiB
-		const size_t per_slice = std::max<size_t>(1, ((size_t)2 << 30) / (cap * sizeof(SimEvent)));
-		std::vector<int> next;
-		for (size_t s0 = 0; s0 < todo.size(); s0 += per_slice) {
-			const size_t cnt = std::min(per_slice, todo.size() - s0);
-			// the slice's units are addressed through offset pointers: unit u of the slice = problem todo[s0 + u]; the kernel
-			// indexes tcodes / unit_len / min_score / rowbuf by blockIdx, so contiguous runs of problem indices are launched together
-			size_t r0 = 0;
-			while (r0 < cnt) {
-				size_t r1 = r0 + 1;
-				while (r1 < cnt && todo[s0 + r1] == todo[s0 + r1 - 1] + 1) r1++;
-				const int first = todo[s0 + r0], nrun = (int)(r1 - r0);
-				HIPOK(d_ev.ensure((size_t)nrun * cap * sizeof(SimEvent)));
-				HIPOK(hipMemsetAsync(d_cnt.p, 0, sizeof(uint32_t) * nrun, E->st));
-				SimFwdArgs a;
-				a.tcodes = d_tc.as<uint8_t>() + (size_t)first * tstride; a.unit_len = d_len.as<int32_t>() + first; a.tstride = tstride;
-				a.qcodes = d_q.as<uint8_t>(); a.m = E->m; a.min_score = d_min.as<int64_t>() + first;
-				a.rowbuf = d_row.as<uint64_t>() + (size_t)first * 2 * row_stride; a.row_stride = row_stride;
-				a.events = d_ev.as<SimEvent>(); a.event_cap = (uint32_t)cap; a.event_count = d_cnt.as<uint32_t>();
-				hipError_t he;
-				{ TimedScope ts(E, 7); he = launch_sim_forward(a, nrun, E->st); }
-				if (he != hipSuccess) return fail(E, FASIM_E_HIP, "sim_forward launch failed: %s", hipGetErrorString(he));
-				std::vector<uint32_t> cnts((size_t)nrun);
-				HIPOK(hipMemcpyAsync(cnts.data(), d_cnt.p, sizeof(uint32_t) * nrun, hipMemcpyDeviceToHost, E->st));
-				HIPOK(hipStreamSynchronize(E->st));
-				for (int u = 0; u < nrun; u++) {
-					const int k = first + u;
-					if (cnts[(size_t)u] > cap) { next.push_back(k); continue; }
-					ev.resize(cnts[(size_t)u]);
-					if (!ev.empty()) {
-						HIPOK(hipMemcpyAsync(ev.data(), d_ev.as<SimEvent>() + (size_t)u * cap, sizeof(SimEvent) * ev.size(), hipMemcpyDeviceToHost, E->st));
-						HIPOK(hipStreamSynchronize(E->st));
-					}
-					// events arrive in (step, lane) order: within one row the columns ascend; a stable bucket pass by row gives
-					// the row-major order addnode needs
-					std::vector<uint32_t> start((size_t)E->m + 2, 0);
-					for (const SimEvent& e : ev) start[(size_t)e.i + 1]++;
-					for (size_t r = 1; r < start.size(); r++) start[r] += start[r - 1];
-					sorted.resize(ev.size());
-					for (const SimEvent& e : ev) sorted[start[(size_t)e.i]++] = e;
-					std::vector<fasim_sim_node> list;
-					sim_replay_nodes(sorted, list);
-					counts[k] = (int32_t)list.size();
-					for (size_t x = 0; x < list.size(); x++) nodes[(size_t)k * FASIM_SIM_K + x] = list[x];
-				}
-				r0 = r1;
-			}
-		}
-		todo.swap(next);
+	std::vector<uint8_t> tc((size_t)nprob * tstride, 4);
+	for (int k = 0; k < nprob; k++) for (int c = 0; c < lens[k]; c++) tc[(size_t)k * tstride + c] = sim_code(targets[offsets[k] + c]);
+	rc = upload(E, E->tcodes, tc.data(), tc.size()); if (rc) return rc;
+	rc = upload(E, E->unit_len, lens, sizeof(int32_t) * nprob); if (rc) return rc;
+	std::vector<std::vector<fasim_sim_node>> lists;
+	rc = sim_forward_units(E, E->tcodes.as<uint8_t>(), tstride, E->unit_len.as<int32_t>(), lens, 0, nprob, min_scores, E->host_threads, lists);
+	if (rc) return rc;
+	for (int k = 0; k < nprob; k++) {
+		counts[k] = (int32_t)lists[(size_t)k].size();
+		for (size_t x = 0; x < lists[(size_t)k].size(); x++) nodes[(size_t)k * FASIM_SIM_K + x] = lists[(size_t)k][x];
 	}
-	if (!todo.empty()) return fail(E, FASIM_E_HIP, "sim_forward: event buffer overflow after the retry");
 	drain_timed(E);
 	return FASIM_OK;
 }
@@ -1331,6 +1373,40 @@ int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t*
 		HIPOK(hipStreamSynchronize(E->st));
 		for (int u = 0; u < B.nunit; u++) if (pre_max[u] == 255) st.stage2_overflow_units++;
 		st.t_stage2_s += now_s() - t0;
+		}
+
+		if (p.classicSim) {
+			// ---- -F: classic SIM instead of fastSIM (Fasim-LongTarget.cpp:420-426): the forward sweep of every unit on the GPU
+			//      (k_sim_forward + node-list replay), traceback / re-sweeps / triplex records on the host threads (host_sim.cpp)
+			t0 = now_s();
+			std::vector<int64_t> mins((size_t)B.nunit);
+			for (int u = 0; u < B.nunit; u++) mins[(size_t)u] = thr[(size_t)u];
+			std::vector<std::vector<fasim_sim_node>> lists;
+			rc = sim_forward_units(E, E->tcodes.as<uint8_t>(), tstride, E->unit_len.as<int32_t>(), B.unit_len.data(), 0, B.nunit, mins.data(),
+				E->host_threads, lists);
+			if (rc) return rc;
+			std::vector<std::vector<HostTriplex>> per_unit((size_t)B.nunit);
+			std::atomic<int> next(0);
+			auto work = [&]() {
+				std::string target, src;
+				for (;;) {
+					const int u = next.fetch_add(1);
+					if (u >= B.nunit) break;
+					const int s = u / nenc, enc = encs[(size_t)(u % nenc)];
+					encode_unit_host(dna + sidx[(size_t)s] * step, slen[(size_t)s], enc, target, src);
+					sim_finish_unit(E->rna, target, src, (long)(sidx[(size_t)s] * step), thr[(size_t)u], enc, p, lists[(size_t)u], per_unit[(size_t)u]);
+					for (HostTriplex& t : per_unit[(size_t)u]) { t.seg = (int)sidx[(size_t)s]; t.enc = enc; }
+				}
+			};
+			const int nt = std::max(1, std::min(E->host_threads, B.nunit));
+			if (nt == 1) work();
+			else { std::vector<std::thread> th; for (int k = 0; k < nt; k++) th.emplace_back(work); for (auto& t : th) t.join(); }
+			for (int u = 0; u < B.nunit; u++)
+				for (HostTriplex& t : per_unit[(size_t)u])
+					if (t.score >= p.scoreMin && t.identity >= p.minIdentity && t.tri_score >= p.minStability && t.nt >= p.cLength)   // Fasim-LongTarget.cpp:589-597
+						all.push_back(std::move(t));
+			st.t_stage3_s += now_s() - t0;
+			return FASIM_OK;
 		}
 
 		// ---- candidates (a7) and the window tries (a8).  fastSIM() decides on sw_score and ref_end only

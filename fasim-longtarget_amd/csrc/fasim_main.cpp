@@ -19,7 +19,8 @@
 //   resident (fasim_scan_queries) and gets its own output set.  A single-record -f2 behaves exactly like the reference.
 //
 // Differences, all documented in DESIGN.md: without --all-records / --accumulate-records only the first record of a
-// multi-record DNA file is scanned; -F (classic SIM) and -d are not supported.
+// multi-record DNA file is scanned; -d is parsed and ignored as in the reference.  -F (classic SIM): the forward sweep runs
+// on the GPU, the rest of SIM() on host threads (first version of that path).
 #include <getopt.h>
 
 #include <algorithm>
@@ -239,7 +240,7 @@ int main(int argc, char* const* argv)
 		case 'D': p.cDistance = atoi(optarg); break;
 		case 'E': p.cLength = atoi(optarg); break;
 		case 'C': break;                                  // -cn only picked a result vector in the reference (:129-163); see --devices
-		case 'F': fprintf(stderr, "fasim: -F (classic SIM) is outside the accelerated path\n"); return 2;
+		case 'F': p.classicSim = 1; break;                // doFastSim = false (Fasim-LongTarget.cpp:360-362): SIM() instead of fastSIM()
 		case 'd': break;
 		case 1001: devices.assign(1, atoi(optarg)); break;
 		case 1002: stats = true; break;

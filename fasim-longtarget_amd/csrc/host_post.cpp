@@ -136,7 +136,7 @@ bool window_for_try(int it, int cand_score, int cand_pos, int* cutlength)
 }
 
 // ---- a12/a13: triplex record from an alignment (fastsim.h:291-414, 416-560; sim.h:72-97) ------------
-static inline float stability(char c1, char c2, int para)
+float triplex_stability(char c1, char c2, int para)
 {
 	if (para > 0) {
 		if (c1 == 'A' && c2 == 'T') return 3.7; if (c1 == 'T' && c2 == 'G') return 2.8; if (c1 == 'G' && c2 == 'G') return 2.2;
@@ -207,7 +207,7 @@ void convert_triplex(const AlignResult& al, const uint32_t* cigar, const std::st
 		char prev_c = 0, cur = 0;
 		for (int i = 0; i < nt; i++) {
 			cur = (tgt_al[i] == '-') ? '-' : tts[i];
-			v = stability(cur, tfo[i], e.para);
+			v = triplex_stability(cur, tfo[i], e.para);
 			if (cur == prev_c && cur == 'T') { tri = tri - prev_v + p.penaltyT; v = p.penaltyT; }
 			if (cur == prev_c && cur == 'C') { tri = tri - prev_v + p.penaltyC; v = p.penaltyC; }
 			prev_v = v;

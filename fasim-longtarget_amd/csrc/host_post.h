@@ -47,6 +47,11 @@ struct HostTriplex {
 void convert_triplex(const AlignResult& al, const uint32_t* cigar, const std::string& rna, const char* seg, int n, int enc,
 	long dna_start, const fasim_params& p, std::vector<HostTriplex>& list, bool seg_acgtn, bool with_strings = true);
 bool only_acgtn(const char* seg, int n);
+float triplex_stability(char c1, char c2, int para);                    // triplex_score (sim.h:72-97)
+// row f3: everything of SIM() after its first sweep (sim.h:572-1141) for one unit; `nodes` = the node list the forward sweep
+// left (consumed).  Appends the unit's triplexes (nt within [ntMin, ntMax]) in the reference's order.  host_sim.cpp
+void sim_finish_unit(const std::string& rna, const std::string& target, const std::string& src, long dna_start, long min_score,
+	int enc, const fasim_params& p, std::vector<fasim_sim_node>& nodes, std::vector<HostTriplex>& out);
 // tail of fastSIM (fastsim.h:273-288): sort/unique/sort/unique/sort, top 50, identity/stability/nt filter
 void dedup_top(std::vector<HostTriplex>& mine, const fasim_params& p, std::vector<HostTriplex>& out);
 

@@ -42,6 +42,7 @@ typedef struct fasim_params {
 	int32_t penaltyC;        /* -pc  0                                     */
 	int32_t cDistance;       /* -ds  15                                    */
 	int32_t cLength;         /* -lg  50                                    */
+	int32_t classicSim;      /* -F   0; 1 = classic SIM instead of fastSIM (doFastSim = false, Fasim-LongTarget.cpp:360-362) */
 } fasim_params;
 
 void fasim_params_default(fasim_params* p);
@@ -98,11 +99,18 @@ int fasim_encode_unit(const char* seg, int32_t n, int32_t enc, char* target, cha
  * (query x target) matrix, every cell above `min_score` fed to the K = 50 node list in row-major order (addnode,
  * sim.h:99-148).  Returns the node list the sweep leaves, in list order: what the reference holds when its traceback
  * loop starts (sim.h:572).  Scores are the reference's x10 values; min_score is compared unscaled, as the reference
- * does (sim.h:567).  The remaining steps of SIM (linear-space traceback, region recomputation) are not on this path yet:
- * `fasim -F` is still refused.  Query and targets: ACGT (other letters score as mismatches; the reference reads an
- * uninitialised table there), at most 8191 long. */
+ * does (sim.h:567).  fasim_scan with params.classicSim = 1 runs the whole -F path: this sweep on the GPU, then the
+ * linear-space traceback, the region re-sweeps and the triplex records on host threads (csrc/host_sim.cpp).
+ * Query and targets: ACGT (other letters score as mismatches; the reference reads an uninitialised table there), at most
+ * 8191 long. */
 typedef struct fasim_sim_node { int64_t score, stari, starj, endi, endj, top, bot, left, right; } fasim_sim_node;
 #define FASIM_SIM_K 50
+typedef struct fasim_result fasim_result;      /* defined below */
+/* Host half of the -F path for ONE unit (pure host code, no device): everything SIM() does after its first sweep
+ * (sim.h:572-1141) for segment `seg` under encoding `enc`, starting from the node list of the forward sweep.  The records
+ * are the unit's triplexes as SIM() appends them (before LongTarget()'s tail filter). */
+int fasim_sim_finish_unit(const char* rna, int32_t m, const char* seg, int32_t n, int32_t enc, int64_t dna_start, int64_t min_score,
+                          const fasim_params* p, const fasim_sim_node* nodes, int32_t nnodes, fasim_result** out);
 int fasim_sim_forward_batch(fasim_engine* e, const char* targets, const int64_t* offsets, const int32_t* lens, int32_t nprob,
                             const int64_t* min_scores, fasim_sim_node* nodes /* [nprob][FASIM_SIM_K] */, int32_t* counts /* [nprob] */);
 
@@ -140,11 +148,11 @@ typedef struct fasim_scan_stats {
 	int64_t tries_skipped;              /* window tries of the reference whose result cannot matter and that were not run */
 } fasim_scan_stats;
 
-typedef struct fasim_result {
+struct fasim_result {
 	fasim_triplex* recs; int64_t count;
 	char* pool; int64_t pool_len;
 	fasim_scan_stats stats;
-} fasim_result;
+};
 
 /* Scans segments [seg_first, seg_first+seg_count) of `dna` (whole sequence of ONE FASTA record, host
  * memory, upper-case ACGTN).  Coordinates in the records are relative to the whole `dna` exactly as in

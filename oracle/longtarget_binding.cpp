@@ -22,7 +22,7 @@ void LongTarget(struct para &paraList, string rnaSequence, string dnaSequence,
     p.overlapLength = paraList.overlapLength; p.ntMin = paraList.ntMin;    p.ntMax = paraList.ntMax;
     p.scoreMin = paraList.scoreMin;    p.minIdentity = paraList.minIdentity; p.minStability = paraList.minStability;
     p.penaltyT = paraList.penaltyT;    p.penaltyC = paraList.penaltyC;
-    p.cDistance = paraList.cDistance;  p.cLength = paraList.cLength;
+    p.cDistance = paraList.cDistance;  p.cLength = paraList.cLength;   p.classicSim = paraList.doFastSim ? 0 : 1;   // -F
 
     fasim_result *r = NULL;
     if (fasim_scan(eng, dnaSequence.data(), (int64_t)dnaSequence.size(), 0, -1, &p, &r) != FASIM_OK) {

@@ -692,3 +692,57 @@ def test_full_size_50mb_reference_validated_digest_and_sharding_invariance(mod, 
     merged = mod.merge_results(parts)
     assert merged.count == whole.count and merged.recs == whole.recs and merged.pool == whole.pool
     e.close()
+
+
+def _simscan_expected(golden_dir, name, c_length):
+    """fixture X lines of every unit, with LongTarget()'s tail filter applied (Fasim-LongTarget.cpp:589-597; SIM() itself only
+    filters on nt), as scan() tuples"""
+    import struct
+    out, seg, enc = [], 0, 0
+    for line in helpers.gunzip(os.path.join(golden_dir, name)).decode().splitlines():
+        f = line.split(" ")
+        if f[0] == "V":
+            seg, enc = int(f[1]), int(f[2])
+        elif f[0] == "X":
+            ident = struct.unpack("<f", struct.pack("<I", int(f[10], 16)))[0]
+            tri = struct.unpack("<f", struct.pack("<I", int(f[11], 16)))[0]
+            if float(int(f[9])) >= 0.0 and ident >= 60.0 and tri >= 1.0 and int(f[8]) >= c_length:
+                out.append((int(f[1]), int(f[2]), int(f[3]), int(f[4]), int(f[5]), int(f[6]), int(f[7]), int(f[8]), int(f[9]),
+                            int(f[10], 16), int(f[11], 16), f[12].encode(), f[13].encode(), seg, enc))
+    return out
+
+
+def test_classic_sim_scan_end_to_end(mod, h19, golden_dir):
+    """-F through fasim_scan (params.classicSim): forward sweep on the GPU, traceback / re-sweeps / triplex records on the host;
+    every record of every unit equals the reference's own SIM() (ref_probe simscan fixtures), demo and planted 12 kb."""
+    e = mod.Engine(0)
+    e.set_query(h19)
+    p = mod.default_params(classicSim=1, cLength=20)
+    _, dna = synth.read_fasta(os.path.join(golden_dir, "testDNA.fa"))
+    res = e.scan(dna, p)
+    exp = _simscan_expected(golden_dir, "demoF.simscan.gz", 20)
+    assert len(exp) > 100 and res.triplexes() == exp
+    assert res.stats["kernel_launches"][7] > 0, "k_sim_forward must have run"
+    dna2 = synth.planted_dna(12000, 909, h19, every=700)
+    res = e.scan(dna2, p)
+    assert res.triplexes() == _simscan_expected(golden_dir, "simF12k.simscan.gz", 20)
+    e.close()
+
+
+def test_cli_classic_sim_writes_reference_files(golden_dir, tmp_path):
+    """`fasim -F -lg 40` on the demo, and the reference's own driver with the LongTarget() binding and -F: both write the files
+    `fasim_ref -F` writes."""
+    exes = [os.path.join(entry.PKG_DIR, "fasim")]
+    hb = os.path.join(entry.ROOT, "oracle", "_ref", "fasim_ref_hipbind")
+    if os.access(hb, os.X_OK):
+        exes.append(hb)
+    for k, exe in enumerate(exes):
+        wd = tmp_path / f"run{k}"
+        (wd / "out").mkdir(parents=True)
+        for f in ("H19.fa", "testDNA.fa"):
+            (wd / f).write_bytes(open(os.path.join(golden_dir, f), "rb").read())
+        subprocess.run([exe, "-f1", "testDNA.fa", "-f2", "H19.fa", "-O", "out/", "-lg", "40", "-F"], cwd=wd, check=True, stdout=subprocess.DEVNULL)
+        assert (wd / "out" / "hg19-H19-testDNA-TFOsorted").read_bytes() == open(os.path.join(golden_dir, "demoF_lg40.TFOsorted"), "rb").read(), exe
+        for level in (1, 2):
+            got = (wd / "out" / f"hg19-H19-testDNA-TFOclass{level}-15-40").read_bytes()
+            assert got == open(os.path.join(golden_dir, f"demoF_lg40.TFOclass{level}"), "rb").read(), exe

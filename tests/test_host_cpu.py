@@ -64,6 +64,37 @@ def test_integration_md_binding_is_the_compiled_text():
         assert os.access(os.path.join(entry.ROOT, "oracle", "_ref", "fasim_ref_hipbind"), os.X_OK), "run `make -C oracle ref`"
 
 
+def test_classic_sim_host_half_against_reference_units(oracle_build, golden_dir):
+    """Row f3, host half (csrc/host_sim.cpp: traceback, region re-sweeps, triplex records): fed with the node list of the
+    forward sweep (here from the oracle; on the GPU box from k_sim_forward) it must reproduce the reference's own SIM() output
+    for the unit (tests/golden/demoF.simscan.gz), identity / stability as float bits."""
+    m = _mod()
+    o = helpers.Oracle(oracle_build)
+    _, rna = synth.read_fasta(os.path.join(golden_dir, "H19.fa"))
+    _, dna = synth.read_fasta(os.path.join(golden_dir, "testDNA.fa"))
+    units, cur = {}, None
+    for line in helpers.gunzip(os.path.join(golden_dir, "demoF.simscan.gz")).decode().splitlines():
+        f = line.split(" ")
+        if f[0] == "V":
+            cur = units.setdefault(int(f[2]), {"thr": int(f[9]), "x": []})
+        elif f[0] == "X":
+            cur["x"].append((int(f[1]), int(f[2]), int(f[3]), int(f[4]), int(f[5]), int(f[6]), int(f[7]), int(f[8]), int(f[9]),
+                             int(f[10], 16), int(f[11], 16), f[12].encode(), f[13].encode()))
+    assert len(units) == 48
+    p = m.default_params()
+    checked = 0
+    for enc in (0, 1, 12, 13, 26, 47):
+        t, _ = o.encode_unit(dna, enc)
+        thr = units[enc]["thr"]
+        assert thr == int(o.stage1_max(rna, t) * 0.8)
+        nodes = o.sim_forward_nodes(rna, t, thr)
+        res = m.sim_finish_unit(rna, dna, enc, 0, thr, nodes, p)
+        got = [x[:13] for x in res.triplexes()]
+        assert got == units[enc]["x"], (enc, len(got), len(units[enc]["x"]))
+        checked += len(got)
+    assert checked > 50
+
+
 def test_native_merge_rebases_offsets():
     """fasim_merge_results (host half of the exchange step): concatenation in the order given, pool offsets rebased."""
     import time
