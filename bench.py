@@ -58,7 +58,7 @@ VALU_PK16_NOMINAL_TOPS = 256 * 4 * 64 / 4 * 2.4e9 / 1e12
 VALU_PLAIN_PEAK_TOPS = 256 * 4 * 64 / 2 * 2.4e9 / 1e12
 KERNEL_NAMES = ["k_scan (fused stage 1+2)", "k_striped<PRE|MAX1> (stage 1/2 hazard re-runs)", "k_align_fwd (stage 3 forward)",
                 "k_finish_lds (reverse pass + traceback)", "k_encode/k_scan_post/k_hits/k_build_stream",
-                "k_striped<ALIGN|REV> (stage 3 exact replays)", "k_finish/k_banded (global scratch)", "-"]
+                "k_striped<ALIGN|REV> (stage 3 exact replays)", "k_finish/k_banded (global scratch)", "k_sim_forward (-F only)"]
 # packed VALU instructions per DP cell of the variants that are launched by default:
 #   k_scan<RP,PAIR=false>: perm, add, 3 x max, 3 x sat-sub, 2 x max = 10 per row pair = 5.0 per cell
 #   k_align_fwd<RP,TAINT,PAIR=false>: the same + the row-key OR = 11 per row pair = 5.5 per cell

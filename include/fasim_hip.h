@@ -138,7 +138,7 @@ typedef struct fasim_scan_stats {
 	/* HIP-event time of the kernels, summed over launches (each on the stream it was launched on; with several
 	 * batches in flight the durations include sharing the GPU).  index: 0 k_scan (fused stage 1+2), 1 k_striped
 	 * stage-1/2 (hazard re-runs, long queries), 2 k_align_fwd, 3 k_finish_lds, 4 encode/hits/post/stream,
-	 * 5 k_striped stage 3 (exact replays, exact reverse passes), 6 k_finish (global scratch) + k_banded, 7 unused */
+	 * 5 k_striped stage 3 (exact replays, exact reverse passes), 6 k_finish (global scratch) + k_banded, 7 k_sim_forward (-F) */
 	double  kernel_ms[8];
 	int64_t kernel_launches[8];
 	int64_t cells_stage1, cells_stage2, cells_stage3;   /* DP cells actually executed (stage 3: fwd + rev)   */
