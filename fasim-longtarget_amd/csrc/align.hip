@@ -420,16 +420,18 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st)
 	hipError_t err = hipMemsetAsync(a.counter, 0, sizeof(uint32_t), st);
 	if (err != hipSuccess) return err;
 	// (the host sizes the tasks so that there are about 3072 of them: one task per wave, workgroups are short-lived)
-	constexpr int WPB = PAIR ? 16 : FWD_THREADS / 64;
+	// FASIM_FWD_THREADS=256 restores the round-1 shape (4 waves per workgroup, LDS then allows 3 workgroups = 3 waves per SIMD)
+	static const int fwd_threads = [] { const char* e = getenv("FASIM_FWD_THREADS"); const int v = e ? atoi(e) : FWD_THREADS; return (v == 256 || v == 512) ? v : FWD_THREADS; }();
+	const int WPB = PAIR ? 16 : fwd_threads / 64;
 	long blocks = ((long)a.ntask + WPB - 1) / WPB;
-	const long cap = PAIR ? 256 : 256 * (16 / WPB);
+	const long cap = PAIR ? 256 : (WPB == 4 ? 256 * 3 : 256 * 2);
 	if (blocks > cap) blocks = cap;
 	const size_t lds = PAIR ? (size_t)FP_LDS : (size_t)6 * AL_CODE_STRIDE;
 	if (PAIR) {
 		static bool attr_set = false;
 		if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_align_fwd<RP, TAINT, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
 	}
-	hipLaunchKernelGGL((k_align_fwd<RP, TAINT, PAIR>), dim3((unsigned)blocks), dim3(PAIR ? 1024 : FWD_THREADS), lds, st, a);
+	hipLaunchKernelGGL((k_align_fwd<RP, TAINT, PAIR>), dim3((unsigned)blocks), dim3(PAIR ? 1024 : fwd_threads), lds, st, a);
 	return hipGetLastError();
 }
 

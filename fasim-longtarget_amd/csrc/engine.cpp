@@ -15,6 +15,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <memory>
 #include <string>
 #include <condition_variable>
 #include <mutex>
@@ -88,12 +90,16 @@ struct fasim_engine {
 	int host_threads_total = 1;
 	int opt_workers = 0, opt_seg_batch = 0;      // fasim_set_option overrides (0 = default / environment)
 	int opt_taper = -1, opt_gate = -1;           // (-1 = default / environment)
+	int opt_tail_split = 0, opt_tail_items = -1; // cooperative tail: sub-tasks per batch (0 = default 4), batches at the end whose stage 3 is shared (-1 = default: one per worker)
 	bool query_acgt = true;       // query holds only A,C,G,T: stage-1 and stage-2 scoring coincide on N-free segments
 	bool scan_v1 = false;         // FASIM_SCAN_V1=1: force the stripe-faithful kernels for stages 1 and 2
 	int host_threads = 1;
 	// resident DNA record (fasim_load_dna)
 	std::string dna_host;
 	DevBuf dna_res;
+	// stage 3 reads target codes through this view: normally the engine's own `tcodes`, during a stolen sub-task (cooperative
+	// tail of a scan) the resident codes of the batch's owner
+	const uint8_t* tc_view = nullptr;
 	// streaming ingest (fasim_scan with a host buffer): pinned staging buffer of this worker's current batch slice
 	void* pin_dna = nullptr; size_t pin_cap = 0;
 	// HIP-event timing of kernel launches on `st`
@@ -433,6 +439,7 @@ int run_scan_v2(fasim_engine* E, const UnitBatch& B, const std::vector<char>& un
 }
 
 struct WindowProb { int unit, t0, len; };
+static inline const uint8_t* tcv(const fasim_engine* E) { return E->tc_view ? E->tc_view : E->tcodes.as<uint8_t>(); }
 
 int run_finish(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, const std::vector<FwdOut>& fo,
 	std::vector<AlignResult>& out, std::vector<uint32_t>& cigars, std::vector<char>& status);
@@ -453,7 +460,7 @@ int run_align(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>
 		probs[k].q_len = E->m; probs[k].unit = k; probs[k].aux = 0; probs[k].pad = 0;
 	}
 	HIPOK(E->ends.ensure(sizeof(AlignEnds) * n));
-	int rc = run_striped(E, MODE_ALIGN, false, probs, false, E->tcodes.as<uint8_t>(), E->m);
+	int rc = run_striped(E, MODE_ALIGN, false, probs, false, tcv(E), E->m);
 	if (rc) return rc;
 	std::vector<AlignEnds> ends(n);
 	HIPOK(hipMemcpyAsync(ends.data(), E->ends.p, sizeof(AlignEnds) * n, hipMemcpyDeviceToHost, E->st));
@@ -478,7 +485,7 @@ int run_align(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>
 		} else {
 			std::vector<StripedProb> wp(redo.size());
 			for (size_t r = 0; r < redo.size(); r++) { wp[r] = probs[redo[r]]; wp[r].unit = (int)r; }
-			rc = run_striped(E, MODE_ALIGN, true, wp, false, E->tcodes.as<uint8_t>(), E->m);
+			rc = run_striped(E, MODE_ALIGN, true, wp, false, tcv(E), E->m);
 			if (rc) return rc;
 			std::vector<AlignEnds> we(redo.size());
 			HIPOK(hipMemcpyAsync(we.data(), E->ends.p, sizeof(AlignEnds) * redo.size(), hipMemcpyDeviceToHost, E->st));
@@ -543,7 +550,7 @@ int run_align(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>
 			hipError_t he;
 			{
 				TimedScope ts(E, 6);
-				he = launch_banded(E->tcodes.as<uint8_t>(), E->q2.as<uint8_t>(), E->bprobs.as<BandProb>(), (int)cnt,
+				he = launch_banded(tcv(E), E->q2.as<uint8_t>(), E->bprobs.as<BandProb>(), (int)cnt,
 					E->scratch.as<uint8_t>(), E->bout.as<BandOut>(), E->st);
 			}
 			if (he != hipSuccess) return fail(E, FASIM_E_HIP, "banded kernel launch failed: %s", hipGetErrorString(he));
@@ -613,7 +620,7 @@ int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& 
 	HIPOK(E->fout.ensure(sizeof(FwdOut) * n));
 	GateScope gate(E);
 	if (E->st_heavy != E->st) HIPOK(hipStreamSynchronize(E->st));
-	hipError_t he = launch_build_stream(E->tcodes.as<uint8_t>(), E->fprobs.as<FwdProb>(), n, E->fstream.as<uint8_t>(), E->st_heavy);
+	hipError_t he = launch_build_stream(tcv(E), E->fprobs.as<FwdProb>(), n, E->fstream.as<uint8_t>(), E->st_heavy);
 	if (he != hipSuccess) return fail(E, FASIM_E_HIP, "build_stream launch failed: %s", hipGetErrorString(he));
 	FwdLaunch L;
 	L.stream = E->fstream.as<uint8_t>(); L.probs = E->fprobs.as<FwdProb>(); L.task_first = E->ftasks.as<int32_t>();
@@ -668,7 +675,7 @@ int run_rev_exact(fasim_engine* E, const UnitBatch& B, const std::vector<WindowP
 		probs[i].q_len = fo[k].read_end + 1; probs[i].unit = i; probs[i].aux = fo[k].score; probs[i].pad = 0;
 	}
 	HIPOK(E->ends.ensure(sizeof(AlignEnds) * n));
-	int rc = run_striped(E, MODE_REV, false, probs, false, E->tcodes.as<uint8_t>(), E->m); if (rc) return rc;
+	int rc = run_striped(E, MODE_REV, false, probs, false, tcv(E), E->m); if (rc) return rc;
 	std::vector<AlignEnds> ends(n);
 	HIPOK(hipMemcpyAsync(ends.data(), E->ends.p, sizeof(AlignEnds) * n, hipMemcpyDeviceToHost, E->st));
 	HIPOK(hipStreamSynchronize(E->st));
@@ -714,7 +721,7 @@ int run_finish(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb
 	}
 	HIPOK(E->scratch.ensure((size_t)((n + 63) / 64) * 64 * 2048));
 	{ TimedScope ts(E, 3);
-	he = launch_finish(E->tcodes.as<uint8_t>(), E->q2.as<uint8_t>(), E->fprobs.as<FwdProb>(), E->fout.as<FwdOut>(),
+	he = launch_finish(tcv(E), E->q2.as<uint8_t>(), E->fprobs.as<FwdProb>(), E->fout.as<FwdOut>(),
 		E->forder.as<int32_t>(), n, E->scratch.as<uint8_t>(), E->aout.as<AlignOutDev>(), E->cigpool.as<uint32_t>(), (uint32_t)pool_cap,
 		E->cigcount.as<uint32_t>(), E->st); }
 	if (he != hipSuccess) return fail(E, FASIM_E_HIP, "finish launch failed: %s", hipGetErrorString(he));
@@ -739,7 +746,7 @@ int run_finish(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb
 			for (size_t b0 = 0; b0 < big.size(); b0 += per_launch) {
 				const size_t cnt = std::min(per_launch, big.size() - b0);
 				{ TimedScope ts(E, 6);
-				he = launch_finish_big(E->tcodes.as<uint8_t>(), E->q2.as<uint8_t>(), E->fprobs.as<FwdProb>(), E->fout.as<FwdOut>(),
+				he = launch_finish_big(tcv(E), E->q2.as<uint8_t>(), E->fprobs.as<FwdProb>(), E->fout.as<FwdOut>(),
 					E->unit_ids.as<int32_t>() + b0, (int)cnt, E->scratch2.as<uint8_t>(), caps[pass], E->aout.as<AlignOutDev>(),
 					E->cigpool.as<uint32_t>(), (uint32_t)pool_cap, E->cigcount.as<uint32_t>(), E->st); }
 				if (he != hipSuccess) break;
@@ -921,6 +928,8 @@ int fasim_set_option(fasim_engine* E, const char* key, int32_t value)
 	else if (!strcmp(key, "seg_batch")) E->opt_seg_batch = value > 0 ? value : 0;
 	else if (!strcmp(key, "taper")) E->opt_taper = value;          // percent of the segments scanned in half-size batches at the end (-1: default)
 	else if (!strcmp(key, "heavy_gate")) E->opt_gate = value;      // k_scan / k_align_fwd launches in flight at once (0: no gate, -1: default)
+	else if (!strcmp(key, "tail_split")) E->opt_tail_split = value > 0 ? value : 0;
+	else if (!strcmp(key, "tail_items")) E->opt_tail_items = value;
 	else return fail(E, FASIM_E_ARG, "unknown option %s", key);
 	return FASIM_OK;
 }
@@ -1263,15 +1272,34 @@ void fasim_synth_dna(char* out, int64_t n, uint64_t seed)
 // ---- the batched body of LongTarget() ---------------------------------------------------------------
 // One batch of segments [b0, b1) on one worker engine (own stream and buffers): encode, scan, candidates, window
 // alignments, triplex records.  Several batches run concurrently on different workers (fasim_scan below).
+// What one batch leaves after its scan phase (stages 1+2) and what its stage 3 needs: host-side hit lists and segment
+// tables, plus a pointer to the target codes that stay resident on the owner engine.  Stage 3 is separable by unit range
+// (stage3_range), so near the end of a scan a batch publishes its stage 3 as sub-tasks that idle workers take over.
+struct BatchCtx {
+	UnitBatch B;
+	int tstride = 0, nenc = 0, nseg = 0;
+	int64_t step = 0;
+	std::vector<int32_t> sstart, slen; std::vector<int64_t> sidx;
+	std::vector<int32_t> hoff, hcnt, thr; std::vector<uint32_t> hits;
+	std::vector<char> seg_acgtn;
+	const uint8_t* tcodes_dev = nullptr;
+	const char* dna = nullptr; const fasim_params* p = nullptr; const std::vector<int>* encs = nullptr;
+	std::vector<std::vector<HostTriplex>> per_unit;     // [unit]: records of the unit after fastSIM's own filter
+	bool stage3_done = false;                           // -F: the whole batch was finished in the scan phase
+};
+
 int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t* dna_dev, int64_t shard_lo, int64_t b0, int64_t b1,
-	const fasim_params& p, const std::vector<int>& encs, int tstride, std::vector<HostTriplex>& all, fasim_scan_stats& st)
+	const fasim_params& p, const std::vector<int>& encs, int tstride, BatchCtx& C, fasim_scan_stats& st)
 {
 	int rc = FASIM_OK;
 	const int64_t step = p.cutLength - p.overlapLength;
 	const int nenc = (int)encs.size();
+	C.B = UnitBatch(); C.tstride = tstride; C.nenc = nenc; C.nseg = 0; C.step = step; C.dna = dna; C.p = &p; C.encs = &encs; C.stage3_done = false;
+	C.per_unit.clear();
 	{
 		// segments of this batch that are not skipped by same_seq()
-		std::vector<int32_t> sstart, slen; std::vector<int64_t> sidx;
+		std::vector<int32_t>& sstart = C.sstart; std::vector<int32_t>& slen = C.slen; std::vector<int64_t>& sidx = C.sidx;
+		sstart.clear(); slen.clear(); sidx.clear();
 		if (!dna_dev) {
 			// Streaming ingest: the record is in host memory only.  The slice this batch needs goes through the worker's
 			// pinned staging buffer and its own stream; with ~10 batches in flight the copy of one batch overlaps the kernels
@@ -1298,7 +1326,8 @@ int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t*
 		}
 		const int nseg = (int)sidx.size();
 		if (!nseg) return FASIM_OK;
-		UnitBatch B; B.nunit = nseg * nenc; B.tstride = tstride; B.unit_len.resize(B.nunit);
+		C.nseg = nseg;
+		UnitBatch& B = C.B; B.nunit = nseg * nenc; B.tstride = tstride; B.unit_len.resize(B.nunit);
 		for (int s = 0; s < nseg; s++) for (int k = 0; k < nenc; k++) B.unit_len[s * nenc + k] = slen[s];
 		st.units += B.nunit;
 		// executed DP cells: the fused k_scan pass serves stage 1 AND stage 2, so it is counted once (as stage 2); stage 1 is
@@ -1317,8 +1346,9 @@ int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t*
 		// ---- stages 1+2: fused systolic scan (scan.hip); stripe-faithful kernels for hazard units, for
 		//      queries beyond 3072 rows, or when FASIM_SCAN_V1=1
 		double t0 = now_s();
-		std::vector<int32_t> hoff, hcnt, thr;
-		std::vector<uint32_t> hits;
+		std::vector<int32_t>& hoff = C.hoff; std::vector<int32_t>& hcnt = C.hcnt; std::vector<int32_t>& thr = C.thr;
+		std::vector<uint32_t>& hits = C.hits;
+		hoff.clear(); hcnt.clear(); thr.clear(); hits.clear();
 		bool done_v2 = false;
 		if (!E->scan_v1) {
 			std::vector<char> need1(B.nunit, E->query_acgt ? 0 : 1);
@@ -1385,7 +1415,8 @@ int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t*
 			rc = sim_forward_units(E, E->tcodes.as<uint8_t>(), tstride, E->unit_len.as<int32_t>(), B.unit_len.data(), 0, B.nunit, mins.data(),
 				E->host_threads, lists);
 			if (rc) return rc;
-			std::vector<std::vector<HostTriplex>> per_unit((size_t)B.nunit);
+			std::vector<std::vector<HostTriplex>>& per_unit = C.per_unit;
+			per_unit.assign((size_t)B.nunit, std::vector<HostTriplex>());
 			std::atomic<int> next(0);
 			auto work = [&]() {
 				std::string target, src;
@@ -1401,13 +1432,35 @@ int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t*
 			const int nt = std::max(1, std::min(E->host_threads, B.nunit));
 			if (nt == 1) work();
 			else { std::vector<std::thread> th; for (int k = 0; k < nt; k++) th.emplace_back(work); for (auto& t : th) t.join(); }
-			for (int u = 0; u < B.nunit; u++)
-				for (HostTriplex& t : per_unit[(size_t)u])
-					if (t.score >= p.scoreMin && t.identity >= p.minIdentity && t.tri_score >= p.minStability && t.nt >= p.cLength)   // Fasim-LongTarget.cpp:589-597
-						all.push_back(std::move(t));
 			st.t_stage3_s += now_s() - t0;
+			C.stage3_done = true;
 			return FASIM_OK;
 		}
+		// the scan phase ends here: stage 3 runs per unit range (stage3_range), on this engine or on helpers
+		C.tcodes_dev = E->tcodes.as<uint8_t>();
+		C.per_unit.assign((size_t)B.nunit, std::vector<HostTriplex>());
+		C.seg_acgtn.resize((size_t)nseg);
+		for (int s = 0; s < nseg; s++) C.seg_acgtn[(size_t)s] = only_acgtn(dna + sidx[(size_t)s] * step, slen[(size_t)s]) ? 1 : 0;
+	}
+	return FASIM_OK;
+}
+
+// Stage 3 (candidates, window tries, finish kernels, triplex records) for units [ua, ub) of a scanned batch.  Runs on any
+// engine of the device that has the batch's lncRNA set: the target codes are read from the owner's resident buffer.
+int stage3_range(fasim_engine* E, BatchCtx& C, int ua, int ub, fasim_scan_stats& st)
+{
+	int rc = FASIM_OK;
+	const UnitBatch& B = C.B;
+	const fasim_params& p = *C.p;
+	const std::vector<int>& encs = *C.encs;
+	const char* dna = C.dna;
+	const int64_t step = C.step;
+	const int nenc = C.nenc;
+	const std::vector<int32_t>& slen = C.slen; const std::vector<int64_t>& sidx = C.sidx;
+	const std::vector<int32_t>& hoff = C.hoff; const std::vector<int32_t>& hcnt = C.hcnt; const std::vector<uint32_t>& hits = C.hits;
+	struct ViewScope { fasim_engine* e; ViewScope(fasim_engine* e_, const uint8_t* v) : e(e_) { e->tc_view = v; } ~ViewScope() { e->tc_view = nullptr; } } view(E, C.tcodes_dev);
+	double t0;
+	{
 
 		// ---- candidates (a7) and the window tries (a8).  fastSIM() decides on sw_score and ref_end only
 		//      (fastsim.h:218-235); both are known after the FORWARD pass (the reverse pass returns the same
@@ -1422,11 +1475,11 @@ int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t*
 		{
 			ProfScope ps(7, "pick candidates");
 			// contiguous unit ranges on the host threads, concatenated in unit order
-			const int nt = std::max(1, std::min(E->host_threads, B.nunit / 256));
+			const int nt = std::max(1, std::min(E->host_threads, (ub - ua) / 256));
 			std::vector<std::vector<CandState>> part(nt);
 			auto work = [&](int ti) {
 				std::vector<Cand> tmp;
-				const int u0 = (int)((int64_t)B.nunit * ti / nt), u1 = (int)((int64_t)B.nunit * (ti + 1) / nt);
+				const int u0 = ua + (int)((int64_t)(ub - ua) * ti / nt), u1 = ua + (int)((int64_t)(ub - ua) * (ti + 1) / nt);
 				for (int u = u0; u < u1; u++) {
 					pick_candidates(hits.data() + hoff[u], hcnt[u], tmp);
 					for (const Cand& c : tmp) { CandState x; memset(&x.fsel, 0, sizeof x.fsel); memset(&x.fbest, 0, sizeof x.fbest);
@@ -1573,18 +1626,18 @@ int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t*
 
 		// ---- host: triplex records per unit (a12-a14), then LongTarget()'s tail filter (a15)
 		t0 = now_s();
-		std::vector<std::vector<HostTriplex>> per_unit(B.nunit);
-		std::vector<char> seg_acgtn(nseg);
-		for (int s = 0; s < nseg; s++) seg_acgtn[s] = only_acgtn(dna + sidx[s] * step, slen[s]) ? 1 : 0;
+		std::vector<std::vector<HostTriplex>>& per_unit = C.per_unit;      // slots [ua, ub) belong to this call
+		const std::vector<char>& seg_acgtn = C.seg_acgtn;
 		{
-			std::vector<size_t> first(B.nunit + 1, 0);
+			std::vector<size_t> first_((size_t)(ub - ua) + 1, 0);
+			size_t* first = first_.data() - ua;                                // first[u] for u in [ua, ub]
 			for (const CandState& x : cs) first[x.unit + 1]++;
-			for (int u = 0; u < B.nunit; u++) first[u + 1] += first[u];
-			std::atomic<int> next(0);
+			for (int u = ua; u < ub; u++) first[u + 1] += first[u];
+			std::atomic<int> next(ua);
 			auto work = [&]() {
 				for (;;) {
 					const int u = next.fetch_add(1);
-					if (u >= B.nunit) break;
+					if (u >= ub) break;
 					if (first[u] == first[u + 1]) continue;
 					const int s = u / nenc, enc = encs[u % nenc];
 					const char* seg = dna + sidx[s] * step;
@@ -1615,17 +1668,23 @@ int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t*
 					}
 				}
 			};
-			const int nt = std::max(1, std::min(E->host_threads, B.nunit));
+			const int nt = std::max(1, std::min(E->host_threads, ub - ua));
 			if (nt == 1) work();
 			else { std::vector<std::thread> th; for (int k = 0; k < nt; k++) th.emplace_back(work); for (auto& t : th) t.join(); }
 		}
-		for (int u = 0; u < B.nunit; u++)
-			for (HostTriplex& t : per_unit[u])
-				if (t.score >= p.scoreMin && t.identity >= p.minIdentity && t.tri_score >= p.minStability && t.nt >= p.cLength)   // Fasim-LongTarget.cpp:589-597
-					all.push_back(std::move(t));
 		st.t_host_s += now_s() - t0;
 	}
-	return FASIM_OK;
+	return rc;
+}
+
+// LongTarget()'s tail filter (Fasim-LongTarget.cpp:589-597) over the units of a finished batch, in canonical order
+static void collect_batch(BatchCtx& C, std::vector<HostTriplex>& all)
+{
+	const fasim_params& p = *C.p;
+	for (auto& unit : C.per_unit)
+		for (HostTriplex& t : unit)
+			if (t.score >= p.scoreMin && t.identity >= p.minIdentity && t.tri_score >= p.minStability && t.nt >= p.cLength)
+				all.push_back(std::move(t));
 }
 
 // pack the records of one query into the C result
@@ -1779,25 +1838,104 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 		std::vector<double> it0(items.size(), 0.0), it1(items.size(), 0.0);
 		std::vector<int> wrc(ws.size(), FASIM_OK);
 		std::atomic<size_t> next(0);
+		// Cooperative tail.  A worker owns an item through its scan phase (stages 1+2: its engine holds the target codes); the
+		// stage 3 of the LAST `tail_items` items is published as `tail_split` sub-tasks (unit ranges), which the owner and
+		// every worker that has run out of items work off together, so the end of a scan is not one batch's sequential rounds
+		// on an otherwise idle GPU.  Earlier items run their stage 3 as one piece on the owner (fewer, larger launches).
+		static const int env_split = [] { const char* e = getenv("FASIM_TAIL_SPLIT"); return e ? atoi(e) : 4; }();
+		static const int env_tail = [] { const char* e = getenv("FASIM_TAIL_ITEMS"); return e ? atoi(e) : -1; }();
+		const int tail_split = std::max(1, E->opt_tail_split > 0 ? E->opt_tail_split : env_split);
+		const size_t tail_items = (size_t)std::max(0, E->opt_tail_items >= 0 ? E->opt_tail_items : (env_tail >= 0 ? env_tail : nworkers));
+		struct SubTask { size_t item; int ua, ub; };
+		struct BatchRun { BatchCtx ctx; std::atomic<int> pending{ 0 }; std::mutex mu; fasim_scan_stats st3; int rc = FASIM_OK; };
+		std::vector<std::unique_ptr<BatchRun>> runs(items.size());
+		std::mutex pool_mu; std::condition_variable pool_cv; std::deque<SubTask> pool; size_t items_finished = 0;
+		auto do_subtask = [&](fasim_engine* w, const SubTask& t) {
+			BatchRun& R = *runs[t.item];
+			const std::string& rq = queries[(size_t)items[t.item].q];
+			int r = FASIM_OK;
+			if (w->rna != rq) r = fasim_set_query(w, rq.data(), (int)rq.size());
+			fasim_scan_stats local; memset(&local, 0, sizeof local);
+			if (!r) r = stage3_range(w, R.ctx, t.ua, t.ub, local);
+			(void)hipStreamSynchronize(w->st);
+			drain_timed(w);
+			for (int k = 0; k < 8; k++) { local.kernel_ms[k] = w->kernel_ms[k]; local.kernel_launches[k] = w->kernel_launches[k]; w->kernel_ms[k] = 0; w->kernel_launches[k] = 0; }
+			{
+				std::lock_guard<std::mutex> lk(R.mu);
+				add_stats(R.st3, local);
+				if (r && !R.rc) { R.rc = r; if (w != E) E->err = w->err; }
+			}
+			if (R.pending.fetch_sub(1) == 1) { std::lock_guard<std::mutex> lk(pool_mu); pool_cv.notify_all(); }
+		};
 		auto run = [&](size_t wi) {
 			(void)hipSetDevice(E->device);
 			fasim_engine* w = ws[wi];
 			for (;;) {
 				const size_t c = next.fetch_add(1);
-				if (c >= items.size()) break;
+				if (c >= items.size()) {
+					// out of items: help with published stage-3 sub-tasks until every item is finished
+					SubTask t{ 0, 0, 0 }; bool have = false;
+					{
+						std::unique_lock<std::mutex> lk(pool_mu);
+						pool_cv.wait(lk, [&] { return !pool.empty() || items_finished == items.size(); });
+						if (!pool.empty()) { t = pool.front(); pool.pop_front(); have = true; }
+					}
+					if (!have) break;
+					do_subtask(w, t);
+					continue;
+				}
 				const Item& itx = items[c];
 				const std::string& rq = queries[(size_t)itx.q];
 				it0[c] = now_s();
-				if (w->rna != rq) {          // the worker switches to this item's lncRNA (2 x m bytes H2D)
-					const int r = fasim_set_query(w, rq.data(), (int)rq.size());
-					if (r) { if (w != E) w->err = std::string("worker set_query failed: ") + w->err; wrc[wi] = r; break; }
+				runs[c].reset(new BatchRun());
+				BatchRun& R = *runs[c];
+				memset(&R.st3, 0, sizeof R.st3);
+				int r = FASIM_OK;
+				if (w->rna != rq) {          // the worker switches to this item's lncRNA (3 x m bytes H2D)
+					r = fasim_set_query(w, rq.data(), (int)rq.size());
+					if (r && w != E) w->err = std::string("worker set_query failed: ") + w->err;
 				}
-				const int r = scan_batch(w, dna, dna_len, dna_dev, shard_lo, itx.b0, itx.b1, p, encs, tstride, per_item[c], ist[c]);
-				if (r) { wrc[wi] = r; break; }
+				if (!r) r = scan_batch(w, dna, dna_len, dna_dev, shard_lo, itx.b0, itx.b1, p, encs, tstride, R.ctx, ist[c]);
 				(void)hipStreamSynchronize(w->st);
 				drain_timed(w);
 				for (int k = 0; k < 8; k++) { ist[c].kernel_ms[k] = w->kernel_ms[k]; ist[c].kernel_launches[k] = w->kernel_launches[k]; w->kernel_ms[k] = 0; w->kernel_launches[k] = 0; }
+				const int nunit = R.ctx.B.nunit;
+				if (!r && nunit > 0 && !R.ctx.stage3_done) {
+					const bool in_tail = items.size() - c <= tail_items;
+					const int nsub = in_tail ? std::max(1, std::min(tail_split, R.ctx.nseg)) : 1;
+					if (nsub == 1) { R.pending.store(1); do_subtask(w, SubTask{ c, 0, nunit }); }
+					else {
+						std::vector<SubTask> subs;
+						for (int k = 0; k < nsub; k++) {           // whole segments per sub-task
+							const int s0 = (int)((int64_t)R.ctx.nseg * k / nsub), s1 = (int)((int64_t)R.ctx.nseg * (k + 1) / nsub);
+							if (s1 > s0) subs.push_back(SubTask{ c, s0 * R.ctx.nenc, s1 * R.ctx.nenc });
+						}
+						R.pending.store((int)subs.size());
+						{ std::lock_guard<std::mutex> lk(pool_mu); for (const SubTask& t : subs) pool.push_back(t); }
+						pool_cv.notify_all();
+						// the owner works the pool (its own sub-tasks and others') until its batch is complete
+						for (;;) {
+							SubTask t{ 0, 0, 0 }; bool have = false;
+							{
+								std::unique_lock<std::mutex> lk(pool_mu);
+								pool_cv.wait(lk, [&] { return !pool.empty() || R.pending.load() == 0; });
+								if (R.pending.load() == 0) break;
+								if (!pool.empty()) { t = pool.front(); pool.pop_front(); have = true; }
+							}
+							if (have) do_subtask(w, t);
+						}
+					}
+					if (R.rc) r = R.rc;
+				}
+				if (!r) {
+					collect_batch(R.ctx, per_item[c]);
+					add_stats(ist[c], R.st3);
+				}
 				it1[c] = now_s();
+				runs[c].reset();                               // frees the batch's host tables
+				if (r) wrc[wi] = r;
+				{ std::lock_guard<std::mutex> lk(pool_mu); items_finished++; }
+				pool_cv.notify_all();
 			}
 			(void)hipStreamSynchronize(w->st);
 		};
