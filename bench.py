@@ -69,6 +69,17 @@ def _env_on(name):
 OPS_PER_CELL = {"k_scan": 4.5 if _env_on("FASIM_SCAN_PAIR") else 5.0, "k_align_fwd": 5.0 if _env_on("FASIM_FWD_PAIR") else 5.5}
 
 
+def host_cores_uncapped():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def host_cores():
     """cores this process may really use: scheduler affinity, capped by the cgroup CPU quota when there is one"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -176,6 +187,10 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
+    # N ranks share one node's host cores: the engine's default (3/8 of the cores, at most 96 threads for the host side of a
+    # batch) is per process, so divide it among the ranks unless the user has set it
+    if world > 1 and "FASIM_HOST_THREADS" not in os.environ:
+        os.environ["FASIM_HOST_THREADS"] = str(max(8, min(96, host_cores_uncapped() * 3 // 8 // world)))
     mod = entry.load()
     eng = mod.Engine(local)
     rna_path = os.path.join(ROOT, "tests", "golden", "H19.fa")
@@ -350,7 +365,7 @@ def main():
             "ms": {KERNEL_NAMES[i]: round(ik[i], 2) for i in range(7)},
             "dominant_kernel_ms_per_step_equivalent": round(ik[0] * units_per_step / max(1, iso["units"]), 1),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # the CPU baseline is reported at N = 1 only
             cores = args.cpu_cores if args.cpu_cores > 0 else host_cores()
             tmp_rna = None
             cpu_rna = rna_path
