@@ -928,6 +928,7 @@ int fasim_set_option(fasim_engine* E, const char* key, int32_t value)
 	else if (!strcmp(key, "seg_batch")) E->opt_seg_batch = value > 0 ? value : 0;
 	else if (!strcmp(key, "taper")) E->opt_taper = value;          // percent of the segments scanned in half-size batches at the end (-1: default)
 	else if (!strcmp(key, "heavy_gate")) E->opt_gate = value;      // k_scan / k_align_fwd launches in flight at once (0: no gate, -1: default)
+	else if (!strcmp(key, "host_threads")) { if (value > 0) { E->host_threads = value; E->host_threads_total = value; } }   // host side of the batches (all workers together)
 	else if (!strcmp(key, "tail_split")) E->opt_tail_split = value > 0 ? value : 0;
 	else if (!strcmp(key, "tail_items")) E->opt_tail_items = value;
 	else return fail(E, FASIM_E_ARG, "unknown option %s", key);

@@ -270,6 +270,12 @@ int main(int argc, char* const* argv)
 		if (fasim_engine_create(d, &e) != FASIM_OK) { fprintf(stderr, "fasim: %s\n", fasim_last_error(nullptr)); return 1; }
 		engines.push_back(e);
 	}
+	if (engines.size() > 1 && !getenv("FASIM_HOST_THREADS")) {
+		// one process, several engines: divide the default host-thread budget (3/8 of the cores, at most 96) among them
+		const unsigned hc = std::max(1u, std::thread::hardware_concurrency());
+		const int per = std::max(8, (int)std::min(96u, hc * 3 / 8) / (int)engines.size());
+		for (fasim_engine* e : engines) fasim_set_option(e, "host_threads", per);
+	}
 
 	// file name: <O>/<species>-<lncName>-<f1 minus 3 chars>-TFOsorted (:123, 800-802); with --all-records the record's
 	// chr is appended to the stem so that the records of a genome do not overwrite each other
