@@ -746,3 +746,51 @@ def test_cli_classic_sim_writes_reference_files(golden_dir, tmp_path):
         for level in (1, 2):
             got = (wd / "out" / f"hg19-H19-testDNA-TFOclass{level}-15-40").read_bytes()
             assert got == open(os.path.join(golden_dir, f"demoF_lg40.TFOclass{level}"), "rb").read(), exe
+
+
+# ---- edge cases of the round-2 paths ---------------------------------------------------------------------------------------
+def test_scan_queries_mixed_query_classes(mod, golden_dir, h19):
+    """One batch with a 100-nt query (stripe-faithful kernels only), H19 (one systolic tile) and MALAT1 (three tiles): the
+    workers and the helpers of the cooperative tail switch query and kernel variant from item to item; every result equals the
+    scan of that query alone."""
+    _, q100 = synth.read_fasta(os.path.join(golden_dir, "h19_100.fa"))
+    _, malat = synth.read_fasta(os.path.join(golden_dir, "MALAT1.fa"))
+    _, dna = synth.read_fasta(os.path.join(golden_dir, "planted40k.fa"))
+    p = mod.default_params(cLength=30)
+    e = mod.Engine(0)
+    e.set_option("seg_batch", 3)           # several items per query
+    rnas = [q100, h19, malat, h19[:1600]]
+    batch = e.scan_queries(rnas, dna, p)
+    for q, rna in enumerate(rnas):
+        e.set_query(rna)
+        alone = e.scan(dna, p)
+        assert batch[q].recs == alone.recs and batch[q].pool == alone.pool, q
+        assert batch[q].stats["units"] == alone.stats["units"] and batch[q].stats["candidates"] == alone.stats["candidates"]
+    e.close()
+
+
+def test_tiny_and_boundary_records(mod, engine, h19, oracle_build, tmp_path):
+    """DNA records of 20, 4 900, 4 901 and 5 000 nt (segment boundary cases of cutSequence, fastsim.h:71-90) against the oracle."""
+    engine.set_query(h19)
+    p = mod.default_params(cLength=20)
+    rna_fa = tmp_path / "rna.fa"
+    rna_fa.write_bytes(b">H19\n" + h19 + b"\n")
+    for n in (20, 4900, 4901, 5000):
+        dna = synth.planted_dna(max(n, 200), 4000 + n, h19, every=300)[:n]
+        res = engine.scan(dna, p)
+        text = mod.tfosorted(res, "chrT", 1, p)
+        fa = tmp_path / f"d{n}.fa"
+        fa.write_bytes(b">syn|chrT|1-%d\n" % n + dna + b"\n")
+        exp = helpers.oracle_cli(oracle_build, "tfosorted", str(rna_fa), str(fa), "-lg", "20")
+        assert text == exp, n
+        assert res.stats["segments"] == mod.segment_count(n, p)
+
+
+def test_cli_more_device_shards_than_segments(golden_dir, tmp_path):
+    exe = os.path.join(entry.PKG_DIR, "fasim")
+    for f in ("H19.fa", "testDNA.fa"):
+        (tmp_path / f).write_bytes(open(os.path.join(golden_dir, f), "rb").read())
+    (tmp_path / "out").mkdir()
+    subprocess.run([exe, "-f1", "testDNA.fa", "-f2", "H19.fa", "-O", "out/", "-lg", "40", "--devices", "0,0,0,0"], cwd=tmp_path, check=True,
+                   stdout=subprocess.DEVNULL)
+    assert (tmp_path / "out" / "hg19-H19-testDNA-TFOsorted").read_bytes() == open(os.path.join(golden_dir, "demo_lg40.TFOsorted"), "rb").read()
