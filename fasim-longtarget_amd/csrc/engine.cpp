@@ -77,6 +77,7 @@ struct fasim_engine {
 	DevBuf q1, q2, enc_lut, counter, dna, seg_start, seg_len, enc_ids, tcodes, colmax, probs, max_out, unit_len,
 		stage1, hits, hits_total, hit_off, hit_cnt, thr, ends, bprobs, bout, scratch, colmax16, unit_ids, flags, stage1_in, hits2,
 		fprobs, ftasks, fstream, fout, aout, cigpool, cigcount, forder, scratch2, boundary, fboundary, unit_hz,
+		unit_first, hz_cols, hz_plan, hz_base, hz_state, hz_rows, hz_chunk, hz_src, hz_zero,   // chunked hazard re-run
 		qsim, sim_min, sim_row, sim_ev, sim_cnt;      // -F: query codes of the SIM alphabet, thresholds, strip row buffer, events, counters
 	bool align_v1 = false;        // FASIM_ALIGN_V1=1: force the stripe-faithful kernels for stage 3
 	std::vector<fasim_engine*> workers;   // extra engines on the same device: batches in flight concurrently
@@ -297,6 +298,136 @@ struct GateScope {
 	~GateScope() { release(); }
 };
 
+// Stripe-faithful re-run of the hazard units (Q2), cut into column chunks that run in PARALLEL (kernels.hip, "chunked hazard
+// re-run"; scan.hip, DUMP variant).
+//   * Columns before the first step at which k_scan saw a possible taint are exact already: the re-run starts there.
+//   * The rest is cut into up to HAZARD_MAX_CHUNKS chunks of about equal cost (k_hazard_plan).  A quick second k_scan pass
+//     over the hazard units only (the checkpoint pass) leaves the reference's DP state -- H, and the E of the reference's
+//     own recurrence -- at every chunk boundary, as it is when no Q2 deviation is alive; every chunk starts from its
+//     checkpoint at once, in one launch.
+//   * A chunk's result is the reference's if its start state is.  Chunk 0 starts where nothing has deviated yet.  A group
+//     that ends chunk j in exactly the next checkpoint stops: chunk j + 1's own group started from that very state (equal
+//     states have equal futures).  Otherwise a deviation is alive, and the group keeps going through chunk j + 1, j + 2, ...
+//     until its state meets a checkpoint (deviations live for the length of one alignment) or the unit ends.  Every group
+//     writes into a row of its own, so the speculative run of a chunk and the run that came through from the left never
+//     touch the same bytes; the host then picks, chunk by chunk from the left, the row of the group that was exact.
+//   * The overflow rule (Q1: everything from the first column >= 251 on is zero) needs no history: the first exact group
+//     that reports an overflow column ends the unit.
+// Latency of the re-run: the checkpoint pass plus one chunk (plus the length of the longest living deviation) instead of
+// 5 000 sequential columns of the 16-lane emulation.
+int run_hazard_chunked(fasim_engine* E, const UnitBatch& B, const std::vector<int>& hz, const ScanLaunch& Lmain)
+{
+	constexpr int KC = HAZARD_MAX_CHUNKS;
+	const int nh = (int)hz.size();
+	const int rows_total = 16 * ((E->m + 15) / 16);
+	const bool dbg = getenv("FASIM_DEBUG_HAZARD") != nullptr;
+	static const int target = [] { const char* e = getenv("FASIM_HAZARD_CHUNK_COLS"); const int v = e ? atoi(e) : 320; return v < 64 ? 64 : v; }();
+	static const int hot_thr = [] { const char* e = getenv("FASIM_HAZARD_HOT_THR"); return e ? atoi(e) : 144; }();
+	static const int hot_w = [] { const char* e = getenv("FASIM_HAZARD_HOT_W"); const int v = e ? atoi(e) : 20; return v < 1 ? 1 : (v > 32 ? 32 : v); }();
+	static const bool spread = [] { const char* e = getenv("FASIM_HAZARD_SPREAD"); return e ? atoi(e) != 0 : true; }();
+	auto now = [] { return std::chrono::steady_clock::now(); };
+	auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
+	const auto t_begin = now();
+
+	// 1. plan (device), read back for the problem list
+	std::vector<int32_t> ids(hz.begin(), hz.end());
+	int rc = upload(E, E->unit_ids, ids.data(), sizeof(int32_t) * nh); if (rc) return rc;
+	HIPOK(E->hz_plan.ensure(sizeof(int32_t) * (size_t)nh * (KC + 1)));
+	HIPOK(E->hz_cols.ensure(sizeof(int32_t) * (size_t)nh * KC));
+	hipError_t he = launch_hazard_plan(E->unit_ids.as<int32_t>(), nh, E->unit_len.as<int32_t>(), E->unit_first.as<int32_t>(), E->colmax16.as<uint16_t>(),
+		B.tstride, target, hot_thr, hot_w, E->hz_plan.as<int32_t>(), E->hz_cols.as<int32_t>(), E->st);
+	if (he != hipSuccess) return fail(E, FASIM_E_HIP, "hazard plan launch failed: %s", hipGetErrorString(he));
+	std::vector<int32_t> plan((size_t)nh * (KC + 1));
+	HIPOK(hipMemcpyAsync(plan.data(), E->hz_plan.p, sizeof(int32_t) * plan.size(), hipMemcpyDeviceToHost, E->st));
+	HIPOK(hipStreamSynchronize(E->st));
+
+	std::vector<StripedProb> probs;
+	std::vector<int32_t> nchunk((size_t)nh, 0), base((size_t)nh, 0);
+	for (int k = 0; k < nh; k++) {
+		const int32_t* c = &plan[(size_t)k * (KC + 1)];
+		const int n = B.unit_len[(size_t)hz[(size_t)k]];
+		int K = 0;
+		while (K < KC && c[K + 1] >= 0) K++;
+		// the shape the kernels index by: strictly increasing boundaries inside the unit, ending at its last column
+		bool ok = K >= 1 && c[0] >= 0 && c[K] == n;
+		for (int j = 0; j < K && ok; j++) ok = c[j] < c[j + 1];
+		if (!ok) return fail(E, FASIM_E_HIP, "hazard re-run: malformed chunk plan for unit %d", hz[(size_t)k]);
+		nchunk[(size_t)k] = K; base[(size_t)k] = (int32_t)probs.size();
+		for (int j = 0; j < K; j++) {
+			StripedProb q;
+			q.tbase = (int64_t)hz[(size_t)k] * B.tstride; q.t0 = c[j]; q.ref_len = c[j + 1] - c[j]; q.q_len = E->m; q.unit = k; q.aux = j; q.pad = 0;
+			probs.push_back(q);
+		}
+	}
+	const int np = (int)probs.size();
+	rc = upload(E, E->hz_base, base.data(), sizeof(int32_t) * nh); if (rc) return rc;
+
+	// 2. checkpoint pass
+	HIPOK(E->hz_state.ensure((size_t)np * 2 * rows_total * sizeof(uint16_t)));
+	{
+		ScanLaunch L = Lmain;
+		L.unit_ids = E->unit_ids.as<int32_t>(); L.nwork = nh; L.unit_hz = nullptr; L.unit_first = nullptr;
+		L.dump_cols = E->hz_cols.as<int32_t>(); L.dump_base = E->hz_base.as<int32_t>(); L.dump_state = E->hz_state.as<uint16_t>();
+		{ TimedScope ts(E, 1); he = launch_scan(L, E->st); }
+		if (he != hipSuccess) return fail(E, FASIM_E_HIP, "scan (checkpoint pass) launch failed: %s", hipGetErrorString(he));
+	}
+	if (dbg) { HIPOK(hipStreamSynchronize(E->st)); fprintf(stderr, "[hazard] %d units, %d chunks; plan + checkpoint pass done at %.2f ms\n", nh, np, ms_since(t_begin)); }
+
+	// 3. all chunks in one launch
+	HIPOK(E->hz_rows.ensure((size_t)np * B.tstride));
+	HIPOK(E->hz_chunk.ensure(sizeof(int32_t) * 4 * np));
+	rc = upload(E, E->probs, probs.data(), probs.size() * sizeof(StripedProb)); if (rc) return rc;
+	StripedLaunch SL;
+	SL.tcodes = E->tcodes.as<uint8_t>(); SL.qcodes = E->q2.as<uint8_t>(); SL.probs = E->probs.as<StripedProb>(); SL.nprob = np;
+	SL.counter = E->counter.as<uint32_t>(); SL.lut = E->lut2; SL.max_qlen = E->m; SL.colmax = nullptr; SL.max_out = nullptr; SL.ends = nullptr;
+	SL.state = E->hz_state.as<uint16_t>(); SL.state_rows = rows_total; SL.chunk_cols = E->hz_plan.as<int32_t>(); SL.chunk_base = E->hz_base.as<int32_t>();
+	SL.chunk_rows = E->hz_rows.as<uint8_t>(); SL.row_stride = B.tstride; SL.chunk_out = E->hz_chunk.as<int32_t>(); SL.spread = spread;
+	{ TimedScope ts(E, 1); he = launch_striped(MODE_PRE, false, true, SL, E->st); }
+	if (he == hipErrorInvalidValue) return fail(E, FASIM_E_UNSUPPORTED, "query of %d nt does not fit the LDS-resident striped kernel", E->m);
+	if (he != hipSuccess) return fail(E, FASIM_E_HIP, "striped kernel launch failed: %s", hipGetErrorString(he));
+	std::vector<int32_t> co((size_t)4 * np);
+	HIPOK(hipMemcpyAsync(co.data(), E->hz_chunk.p, sizeof(int32_t) * 4 * np, hipMemcpyDeviceToHost, E->st));
+	HIPOK(hipStreamSynchronize(E->st));
+	if (dbg) {
+		std::vector<int> order((size_t)np); for (int x = 0; x < np; x++) order[(size_t)x] = x;
+		std::sort(order.begin(), order.end(), [&](int a, int b) { return co[(size_t)4 * a + 2] > co[(size_t)4 * b + 2]; });
+		long sum = 0; int went_on = 0;
+		for (int x = 0; x < np; x++) { sum += co[(size_t)4 * x + 2]; if (co[(size_t)4 * x] != probs[(size_t)x].aux) went_on++; }
+		fprintf(stderr, "[hazard] chunk launch done at %.2f ms; mean problem time %.3f ms; %d of %d groups went on past their chunk\n", ms_since(t_begin), sum / (double)np / 1e5, went_on, np);
+		for (int r = 0; r < std::min(np, 5); r++) {
+			const int x = order[(size_t)r]; const StripedProb& q = probs[(size_t)x];
+			fprintf(stderr, "[hazard]   slow: unit %d chunk %d..%d of %d, first chunk %d cols: %.3f ms\n", hz[(size_t)q.unit], q.aux, co[(size_t)4 * x], nchunk[(size_t)q.unit], q.ref_len, co[(size_t)4 * x + 2] / 1e5);
+		}
+	}
+
+	// 4. from the left: the group that started chunk j exact covers chunks j .. last(j); the next exact group starts at last(j) + 1
+	std::vector<int32_t> src((size_t)nh * KC, 0), zero_from((size_t)nh, -1);
+	{
+		int x0 = 0;
+		for (int k = 0; k < nh; k++) {
+			const int K = nchunk[(size_t)k];
+			int j = 0;
+			while (j < K) {
+				const int last = co[(size_t)4 * (x0 + j)], ovf = co[(size_t)4 * (x0 + j) + 1];
+				if (last < j || last >= K) return fail(E, FASIM_E_HIP, "hazard re-run: inconsistent chunk report for unit %d", hz[(size_t)k]);
+				for (int r = j; r <= last; r++) src[(size_t)k * KC + r] = j;
+				if (ovf >= 0) { zero_from[(size_t)k] = ovf; for (int r = last + 1; r < K; r++) src[(size_t)k * KC + r] = j; break; }
+				j = last + 1;
+			}
+			x0 += K;
+		}
+	}
+	HIPOK(E->hz_src.ensure(sizeof(int32_t) * (size_t)nh * KC));
+	rc = upload(E, E->hz_src, src.data(), sizeof(int32_t) * src.size()); if (rc) return rc;
+	rc = upload(E, E->hz_zero, zero_from.data(), sizeof(int32_t) * nh); if (rc) return rc;
+	he = launch_hazard_merge(E->colmax16.as<uint16_t>(), E->colmax.as<uint8_t>(), E->unit_ids.as<int32_t>(), nh, E->unit_len.as<int32_t>(),
+		E->hz_plan.as<int32_t>(), E->hz_base.as<int32_t>(), E->hz_src.as<int32_t>(), E->hz_zero.as<int32_t>(), E->hz_rows.as<uint8_t>(), B.tstride, B.tstride, E->st);
+	if (he != hipSuccess) return fail(E, FASIM_E_HIP, "hazard merge launch failed: %s", hipGetErrorString(he));
+	HIPOK(hipStreamSynchronize(E->st));
+	if (dbg) fprintf(stderr, "[hazard] merged at %.2f ms\n", ms_since(t_begin));
+	return FASIM_OK;
+}
+
 // returns 1 when the query does not fit the kernel (caller falls back to the striped kernels)
 int run_scan_v2(fasim_engine* E, const UnitBatch& B, const std::vector<char>& unit_needs_stage1, ScanOut& out,
 	fasim_scan_stats* st)
@@ -338,6 +469,9 @@ int run_scan_v2(fasim_engine* E, const UnitBatch& B, const std::vector<char>& un
 	HIPOK(E->unit_hz.ensure(sizeof(int32_t) * nu));
 	HIPOK(hipMemsetAsync(E->unit_hz.p, 0, sizeof(int32_t) * nu, E->st));
 	L.unit_hz = E->unit_hz.as<int32_t>();
+	HIPOK(E->unit_first.ensure(sizeof(int32_t) * nu));
+	HIPOK(hipMemsetAsync(E->unit_first.p, 0x7f, sizeof(int32_t) * nu, E->st));      // 0x7f7f7f7f = "no taint arose"
+	L.unit_first = E->unit_first.as<int32_t>();
 	if (E->st_heavy != E->st) HIPOK(hipStreamSynchronize(E->st));      // k_encode and the memset above ran on the other stream
 	{
 		GateScope gate(E);
@@ -400,7 +534,11 @@ int run_scan_v2(fasim_engine* E, const UnitBatch& B, const std::vector<char>& un
 		if (st) st->hazard_units += (int64_t)hz.size();
 		HIPOK(E->colmax.ensure((size_t)nu * B.tstride));
 		HIPOK(E->max_out.ensure(sizeof(int32_t) * nu));
-		rc = run_striped(E, MODE_PRE, false, whole_unit_probs(B, E->m, &hz), false, E->tcodes.as<uint8_t>(), E->m); if (rc) return rc;
+		static const bool chunked = [] { const char* e = getenv("FASIM_HAZARD_CHUNKS"); return e ? atoi(e) != 0 : true; }();
+		// (a query of more than one tile of 128 virtual lanes, > 3 072 nt, keeps the whole-unit re-run: the checkpoint pass does not
+		//  hand the restarted F chain from tile to tile)
+		if (chunked && systolic_tiles(E->m) == 1) { rc = run_hazard_chunked(E, B, hz, L); if (rc) return rc; }
+		else { rc = run_striped(E, MODE_PRE, false, whole_unit_probs(B, E->m, &hz), false, E->tcodes.as<uint8_t>(), E->m); if (rc) return rc; }
 		std::vector<int32_t> hzids(hz.begin(), hz.end());
 		rc = upload(E, E->unit_ids, hzids.data(), sizeof(int32_t) * hzids.size()); if (rc) return rc;
 		std::vector<int32_t> off2(nu), cnt2(nu);
@@ -911,6 +1049,7 @@ void fasim_engine_destroy(fasim_engine* e)
 		&e->colmax, &e->probs, &e->max_out, &e->unit_len, &e->stage1, &e->hits, &e->hits_total, &e->hit_off, &e->hit_cnt, &e->thr,
 		&e->ends, &e->bprobs, &e->bout, &e->scratch, &e->dna_res, &e->colmax16, &e->unit_ids, &e->flags, &e->stage1_in, &e->hits2,
 		&e->fprobs, &e->ftasks, &e->fstream, &e->fout, &e->aout, &e->cigpool, &e->cigcount, &e->forder, &e->scratch2, &e->boundary, &e->fboundary, &e->unit_hz,
+		&e->unit_first, &e->hz_cols, &e->hz_plan, &e->hz_base, &e->hz_state, &e->hz_rows, &e->hz_chunk, &e->hz_src, &e->hz_zero,
 		&e->qsim, &e->sim_min, &e->sim_row, &e->sim_ev, &e->sim_cnt };
 	for (auto& t : e->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
 	for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);

@@ -7,6 +7,7 @@ namespace fasim {
 
 enum StripedMode { MODE_PRE = 0, MODE_MAX1 = 1, MODE_ALIGN = 2, MODE_REV = 3 };
 
+constexpr int HAZARD_MAX_CHUNKS = 512;   // column chunks (and checkpoints) per hazard unit in the chunked re-run
 struct StripedLaunch {
 	const uint8_t* tcodes;      // device: target codes
 	const uint8_t* qcodes;      // device: query codes (stage-1 or stage-2 coding), length q_total
@@ -19,6 +20,10 @@ struct StripedLaunch {
 	uint16_t* colmax_w = nullptr;   // MODE_PRE with word == true: u16 column maxima instead
 	int32_t* max_out;           // MODE_PRE / MODE_MAX1: per problem (slot = prob.unit) score, 255 = byte overflow
 	AlignEnds* ends;            // MODE_ALIGN: per problem (slot = index in probs)
+	// chunked hazard re-run (MODE_PRE, byte mode): see StripedArgs in kernels.hip
+	const uint16_t* state = nullptr; int32_t state_rows = 0; const int32_t* chunk_cols = nullptr; const int32_t* chunk_base = nullptr; uint8_t* chunk_rows = nullptr; int32_t row_stride = 0;
+	int32_t* chunk_out = nullptr;
+	bool spread = false;        // one 256-thread workgroup per CU (LDS request padded past half a CU): every wave gets a SIMD of its own
 };
 
 // word == false: 8-bit semantics (16 stripes); word == true: 16-bit semantics (8 stripes)
@@ -36,6 +41,12 @@ hipError_t launch_hits(const uint8_t* colmax, const int32_t* unit_ids, const int
 	int32_t tstride, uint32_t* hits, uint32_t hits_cap, uint32_t* hits_total, int32_t* hit_off, int32_t* hit_cnt,
 	int32_t* thr_out, hipStream_t st);
 
+// chunked hazard re-run (kernels.hip): chunk plan of every hazard unit, and the merge of the groups' private rows
+hipError_t launch_hazard_plan(const int32_t* unit_ids, int32_t nlist, const int32_t* unit_len, const int32_t* unit_first, const uint16_t* colmax16,
+	int32_t tstride, int32_t target, int32_t hot_thr, int32_t hot_w, int32_t* chunk_cols, int32_t* dump_cols, hipStream_t st);
+hipError_t launch_hazard_merge(const uint16_t* colmax16, uint8_t* colmax, const int32_t* unit_ids, int32_t nlist, const int32_t* unit_len,
+	const int32_t* chunk_cols, const int32_t* chunk_base, const int32_t* src_chunk, const int32_t* zero_from, const uint8_t* chunk_rows, int32_t row_stride, int32_t tstride, hipStream_t st);
+
 hipError_t launch_banded(const uint8_t* tcodes, const uint8_t* qcodes, const BandProb* probs, int32_t nprob,
 	uint8_t* scratch, BandOut* out, hipStream_t st);
 
@@ -46,6 +57,10 @@ struct ScanLaunch {
 	uint2* boundary;      // [unit][tstride] hand-over rows between query tiles; needed when systolic_tiles(m) > 1
 	int32_t coarse;       // 1: coarse Q2 test (FASIM_Q2_COARSE=1, for measurements)
 	int32_t* unit_hz;     // [unit], zeroed by the caller: |= 1 when the unit needs the stripe-faithful re-run; may be NULL
+	int32_t* unit_first = nullptr;          // [unit], preset to INT_MAX by the caller: first step at which a Q2 taint could arise
+	const int32_t* dump_cols = nullptr;     // != NULL: checkpoint variant: [nwork][HAZARD_MAX_CHUNKS] columns after which H / E of all rows are dumped
+	const int32_t* dump_base = nullptr;   // [work item]: index of its first checkpoint in dump_state
+	uint16_t* dump_state = nullptr;         // [nwork * 8][2][16 * ceil(m/16)]
 };
 int systolic_vs(int m);
 int systolic_tiles(int m);     // query tiles of 128 virtual lanes x <= 24 rows (1 for m <= 3072)

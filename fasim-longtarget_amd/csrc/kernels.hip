@@ -64,6 +64,19 @@ struct StripedArgs {
 	uint16_t* colmax_w;         // MODE_PRE in word mode: 16-bit column maxima (same indexing as colmax)
 	int32_t* max_out;
 	AlignEnds* ends;
+	// chunked hazard re-run (MODE_PRE, byte).  A problem = chunk `aux` of hazard unit `unit` (index into the hazard list):
+	// columns [c[aux], c[aux + 1]) of the unit, with c = chunk_cols[unit][0 .. HAZARD_MAX_CHUNKS] (-1 after the last entry).
+	// It starts from checkpoint state[chunk_base[unit] + aux] (the zero state if c[aux] == 0) and writes its column
+	// maxima into its OWN row chunk_rows[chunk_base[unit] + aux][column].  At the end of a chunk the DP state is
+	// compared with the next checkpoint: equal -> done (the next chunk's own run starts from exactly this state); different
+	// (a Q2 deviation is still alive) -> the same group keeps going through the next chunk's columns, and so on.
+	const uint16_t* state;      // [idx][2][state_rows]: H then E of every row, 2 * value + taint as k_scan carries them
+	int32_t state_rows;
+	const int32_t* chunk_cols;  // [hazard unit][HAZARD_MAX_CHUNKS + 1]
+	const int32_t* chunk_base;  // [hazard unit]: index of its chunk 0 in state / chunk_rows
+	uint8_t* chunk_rows;        // [chunk_base[unit] + chunk][row_stride]
+	int32_t row_stride;
+	int32_t* chunk_out;         // [problem][4]: {last chunk covered, overflow column or -1, ticks of 10 ns spent, start tick}
 };
 
 __device__ __forceinline__ int group_max16(int v)
@@ -199,7 +212,7 @@ __device__ __forceinline__ int column_word(uint16_t* Hs, uint16_t* Es, const uin
 }
 
 template <int MODE, bool WORD, bool QUIRK>
-__global__ void __launch_bounds__(64) k_striped(StripedArgs a)
+__global__ void __launch_bounds__(256) k_striped(StripedArgs a)
 {
 	extern __shared__ __align__(16) uint8_t lds[];
 	using HT = typename std::conditional<WORD, uint16_t, uint8_t>::type;
@@ -221,6 +234,9 @@ __global__ void __launch_bounds__(64) k_striped(StripedArgs a)
 	int phase = -1;          // -1: fetch a problem; 0: forward pass; 1: reverse pass (MODE_ALIGN)
 	int pi = 0, unit = 0, t0 = 0, refLen = 0, qlen = 0, dir = 0, terminate = 0, segLen = 1;
 	int ci = 0, maxv = 0, end_ref = 0, end_read = 0, tchunk = CODE_N;
+	int hz_unit = 0, hz_chunk = 0, hz_base = 0, pb_chunk0 = 0;   // chunked hazard re-run: hazard-list index, the chunk being worked on, the first one
+	bool st_init = false;
+	uint64_t t_start = 0;
 	int64_t tbase = 0;
 	bool overflow = false, setup = false, qrev = false, shared_q_built = false;
 	AlignEnds res;
@@ -237,6 +253,10 @@ __global__ void __launch_bounds__(64) k_striped(StripedArgs a)
 			tbase = pb.tbase; t0 = pb.t0; refLen = pb.ref_len; qlen = pb.q_len; unit = pb.unit;
 			dir = 0; qrev = false; terminate = WORD ? 65535 : 255;
 			phase = 0; setup = true;
+			if constexpr (MODE == MODE_PRE && !WORD) {
+				st_init = false;
+				if (a.chunk_out) { hz_unit = pb.unit; hz_chunk = pb_chunk0 = pb.aux; hz_base = a.chunk_base[hz_unit]; st_init = t0 > 0; t_start = wall_clock64(); }
+			}
 			res.score_fwd = res.ref_end = res.read_end = res.score_rev = res.ref_begin = res.read_begin = 0;
 			if constexpr (MODE == MODE_REV) {
 				// reverse pass only (sswNew.cpp:1508-1516): the forward result is known and exact
@@ -254,6 +274,12 @@ __global__ void __launch_bounds__(64) k_striped(StripedArgs a)
 				if (!SHARED_Q || g == 0 || !shared_q_built) Qs[j] = (uint8_t)(code * 4);
 				Hs[j] = 0;
 				Es[j] = 0;
+				if constexpr (MODE == MODE_PRE && !WORD) {
+					if (st_init) {                       // resume from a checkpoint: the state after column t0 - 1
+						const uint16_t* sp = a.state + (size_t)(hz_base + hz_chunk) * 2 * a.state_rows;
+						Hs[j] = (HT)(sp[row] >> 1); Es[j] = (HT)(sp[a.state_rows + row] >> 1);
+					}
+				}
 			}
 			shared_q_built = true;               // (all groups write identical bytes the first time: benign)
 			ci = 0; maxv = 0; overflow = false;
@@ -295,7 +321,11 @@ __global__ void __launch_bounds__(64) k_striped(StripedArgs a)
 			}
 			if (!stop) {
 				if constexpr (MODE == MODE_PRE) {
-					if (s == 0) { if constexpr (WORD) a.colmax_w[tbase + t0 + i] = (uint16_t)colmax; else a.colmax[tbase + t0 + i] = (uint8_t)colmax; }
+					if (s == 0) {
+						if constexpr (WORD) a.colmax_w[tbase + t0 + i] = (uint16_t)colmax;
+						else if (a.chunk_out) a.chunk_rows[(size_t)(hz_base + pb_chunk0) * a.row_stride + t0 + i] = (uint8_t)colmax;
+						else a.colmax[tbase + t0 + i] = (uint8_t)colmax;
+					}
 				}
 				if (colmax == terminate) stop = true;
 			}
@@ -306,12 +336,37 @@ __global__ void __launch_bounds__(64) k_striped(StripedArgs a)
 			const int score = (!WORD && overflow) ? 255 : maxv;
 			if constexpr (MODE == MODE_PRE) {
 				if constexpr (!WORD) {
-					if (overflow) {
+					if (a.chunk_out) {
+						// end of chunk hz_chunk: is the state the checkpoint the next chunk's own run started from?
+						const int32_t* cc = a.chunk_cols + (size_t)hz_unit * (HAZARD_MAX_CHUNKS + 1);
+						const int nxt = hz_chunk + 1;
+						const int c_after = (nxt < HAZARD_MAX_CHUNKS) ? cc[nxt + 1] : -1;      // end of the next chunk (-1: there is none)
+						if (!overflow && c_after >= 0) {
+							const uint16_t* sc = a.state + (size_t)(hz_base + nxt) * 2 * a.state_rows;
+							bool differs = false;
+							for (int j = 0; j < segLen; j++) {
+								const int row = s * segLen + j;
+								if ((sc[row] >> 1) != (uint16_t)Hs[j] || (sc[a.state_rows + row] >> 1) != (uint16_t)Es[j]) { differs = true; break; }
+							}
+							if (group_any16(differs)) {
+								// keep going: the deviation is alive.  (the target letters of the 16-column block in flight were
+								// fetched against the old end: again)
+								hz_chunk = nxt; refLen = c_after - t0;
+								const int cc16 = (ci & ~15) + s;
+								tchunk = (cc16 < refLen) ? (int)a.tcodes[tbase + t0 + cc16] : CODE_N;
+								continue;
+							}
+						}
+						if (s == 0) {
+							int32_t* co = a.chunk_out + (size_t)4 * pi;
+							co[0] = hz_chunk; co[1] = overflow ? t0 + ci - 1 : -1; co[2] = (int)(wall_clock64() - t_start); co[3] = (int)(uint32_t)t_start;
+						}
+					} else if (overflow) {
 						// Q1: the overflowing column and everything after it stay 0 (calloc'd array, sswNew.cpp:282)
 						for (int c = (ci - 1) + s; c < refLen; c += 16) a.colmax[tbase + t0 + c] = 0;
 					}
 				}
-				if (s == 0) a.max_out[unit] = score;
+				if (s == 0 && !a.chunk_out) a.max_out[unit] = score;
 				phase = -1;
 			} else if constexpr (MODE == MODE_MAX1) {
 				if (s == 0) a.max_out[unit] = score;
@@ -359,9 +414,13 @@ static hipError_t launch_striped_t(const StripedLaunch& L, hipStream_t st)
 	// FASIM_STRIPED_GROUPS caps the problems per workgroup (default 4): two keep a workgroup's LDS below the ~20 KB that
 	// four k_scan workgroups leave free on a CU, so these latency-bound kernels can start while a scan is running
 	static const int max_groups = [] { const char* e = getenv("FASIM_STRIPED_GROUPS"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
-	if (groups > max_groups) groups = max_groups;
+	if (L.spread) { if (groups > 16) groups = 16; }        // four waves of four problems: the whole CU (see below)
+	else if (groups > max_groups) groups = max_groups;
 	if (groups < 1) return hipErrorInvalidValue;           // query too long for the LDS-resident kernel
-	const size_t shmem = (size_t)groups * gbytes + (SHARED_Q ? qbytes : 0);
+	size_t shmem = (size_t)groups * gbytes + (SHARED_Q ? qbytes : 0);
+	// spread: a request of more than half the CU's LDS keeps the dispatcher from packing several of these workgroups onto one
+	// CU.  A wave of this kernel alone on its SIMD issues back to back; four of them on one SIMD take four times as long.
+	if (L.spread && shmem < (size_t)84 * 1024) shmem = (size_t)84 * 1024;
 	auto kern = k_striped<MODE, WORD, QUIRK>;
 	hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
 	if (err != hipSuccess) return err;
@@ -370,6 +429,7 @@ static hipError_t launch_striped_t(const StripedLaunch& L, hipStream_t st)
 	StripedArgs a;
 	a.tcodes = L.tcodes; a.qcodes = L.qcodes; a.probs = L.probs; a.nprob = L.nprob; a.counter = L.counter;
 	a.lut = L.lut; a.s4 = s4; a.colmax = L.colmax; a.colmax_w = L.colmax_w; a.max_out = L.max_out; a.ends = L.ends;
+	a.state = L.state; a.state_rows = L.state_rows; a.chunk_cols = L.chunk_cols; a.chunk_base = L.chunk_base; a.chunk_rows = L.chunk_rows; a.row_stride = L.row_stride; a.chunk_out = L.chunk_out;
 	// enough one-wave workgroups to fill the chip at the LDS-limited occupancy; the queue balances the rest
 	int per_cu = (int)((160 * 1024) / shmem);
 	if (per_cu < 1) per_cu = 1;
@@ -397,6 +457,103 @@ hipError_t launch_striped(StripedMode mode, bool word, bool quirk, const Striped
 	}
 	(void)quirk;
 	return hipErrorInvalidValue;
+}
+
+// ---- chunked hazard re-run: planning and merging (one wave per hazard unit) ------------------------------------------
+// k_hazard_plan: where the stripe-faithful re-run of a unit starts and how its columns are cut into chunks.
+//   * start f = first pipeline step at which k_scan saw a possible Q2 taint, minus the 127 columns the pipeline holds: the
+//     column maxima before f are the reference's already (k_hazard_merge copies them).
+//   * [f, n) is cut into K <= HAZARD_MAX_CHUNKS chunks of about equal COST.  A column whose maximum reaches `hot_thr` is
+//     priced `hot_w` times a plain one: there the reference's lazy-F loop keeps running (H - gapO >= 128 reads as negative
+//     in its signed compare, sswNew.cpp:369), and so does the emulation.
+// chunk_cols[k][0 .. K] = chunk boundaries (c[0] = f, c[K] = n, -1 beyond); dump_cols[k][j] = c[j] - 1 = the column after
+// which the checkpoint pass (k_scan<.., DUMP>) leaves the DP state chunk j starts from (-1: none).
+__global__ void __launch_bounds__(64) k_hazard_plan(const int32_t* __restrict__ unit_ids, const int32_t* __restrict__ unit_len,
+	const int32_t* __restrict__ unit_first, const uint16_t* __restrict__ colmax16, int32_t tstride, int32_t target, int32_t hot_thr, int32_t hot_w,
+	int32_t* __restrict__ chunk_cols, int32_t* __restrict__ dump_cols)
+{
+	constexpr int KC = HAZARD_MAX_CHUNKS;
+	const int k = blockIdx.x, lane = threadIdx.x, unit = unit_ids[k], n = unit_len[unit];
+	const int fs = unit_first[unit];
+	const int f = fs >= 0x7f000000 ? 0 : max(0, min(n - 1, fs - 127));
+	const uint16_t* src = colmax16 + (int64_t)unit * tstride;
+	auto weight = [&](int c) { return ((int)(src[c] >> 1) >= hot_thr) ? hot_w : 1; };
+	const int B = (n - f + 63) / 64;
+	const int c0 = min(n, f + lane * B), c1 = min(n, c0 + B);
+	int wsum = 0;
+	for (int c = c0; c < c1; c++) wsum += weight(c);
+	int incl = wsum;
+	for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+	const int W = max(1, __shfl(incl, 63, 64));
+	const int K = max(1, min(KC, (W + target - 1) / target));
+	int32_t* cc = chunk_cols + (size_t)k * (KC + 1);
+	int32_t* dc = dump_cols + (size_t)k * KC;
+	if (lane == 0) { cc[0] = f; dc[0] = f - 1; }
+	for (int j = K + lane; j <= KC; j += 64) { cc[j] = j == K ? n : -1; if (j < KC) dc[j] = -1; }
+	// boundary q = the first column whose exclusive cost prefix p satisfies floor(p * K / W) >= q  (W / K > hot_w: the quotient
+	// moves by at most one per column)
+	int p = incl - wsum;
+	int qlast = (c0 > f && c0 < n) ? (int)(((int64_t)(p - weight(c0 - 1)) * K) / W) : 0;
+	for (int c = c0; c < c1; c++) {
+		const int q = (int)(((int64_t)p * K) / W);
+		if (q > qlast && q < K) { cc[q] = c; dc[q] = c - 1; }
+		qlast = q;
+		p += weight(c);
+	}
+}
+
+hipError_t launch_hazard_plan(const int32_t* unit_ids, int32_t nlist, const int32_t* unit_len, const int32_t* unit_first, const uint16_t* colmax16,
+	int32_t tstride, int32_t target, int32_t hot_thr, int32_t hot_w, int32_t* chunk_cols, int32_t* dump_cols, hipStream_t st)
+{
+	if (nlist <= 0) return hipSuccess;
+	hipLaunchKernelGGL(k_hazard_plan, dim3((unsigned)nlist), dim3(64), 0, st, unit_ids, unit_len, unit_first, colmax16, tstride, target, hot_thr, hot_w,
+		chunk_cols, dump_cols);
+	return hipGetLastError();
+}
+
+// k_hazard_merge: the u8 column maxima of a hazard unit, put together from
+//   * columns [0, c[0]): the systolic result (u16: 2 * max + taint -> u8) -- no taint could arise before c[0];
+//   * chunk r: the private row of the group that covered it (src_chunk[k][r]: the chunk that group STARTED with; a group whose
+//     end state differed from the next checkpoint has kept going through the following chunks);
+//   * the overflow rule (Q1, sswNew.cpp:386): the first column whose maximum reaches 255 - bias and everything after it are 0.
+//     zero_from[k] = the overflow column a valid group reported (-1: none); an overflow inside the prefix is found here.
+__global__ void __launch_bounds__(64) k_hazard_merge(const uint16_t* __restrict__ colmax16, uint8_t* __restrict__ colmax, const int32_t* __restrict__ unit_ids,
+	const int32_t* __restrict__ unit_len, const int32_t* __restrict__ chunk_cols, const int32_t* __restrict__ chunk_base, const int32_t* __restrict__ src_chunk, const int32_t* __restrict__ zero_from,
+	const uint8_t* __restrict__ chunk_rows, int32_t row_stride, int32_t tstride)
+{
+	constexpr int KC = HAZARD_MAX_CHUNKS;
+	const int k = blockIdx.x, unit = unit_ids[k], n = unit_len[unit];
+	const uint16_t* src = colmax16 + (int64_t)unit * tstride;
+	uint8_t* dst = colmax + (int64_t)unit * tstride;
+	const int32_t* cc = chunk_cols + (size_t)k * (KC + 1);
+	const int up = cc[0];
+	int zf = zero_from[k];
+	int pf = 0x7fffffff;
+	for (int c = threadIdx.x; c < up; c += 64) if ((int)(src[c] >> 1) + BIAS >= 255) { pf = c; break; }
+	for (int o = 32; o; o >>= 1) pf = min(pf, __shfl_xor(pf, o, 64));
+	if (pf != 0x7fffffff) zf = pf;
+	for (int c = threadIdx.x; c < n; c += 64) {
+		int v;
+		if (zf >= 0 && c >= zf) v = 0;
+		else if (c < up) v = (int)(src[c] >> 1);
+		else {
+			// the chunk that holds column c: the last r with cc[r] <= c (boundaries ascend, -1 after the last one)
+			int lo = 0, hi = KC - 1;
+			while (lo < hi) { const int mid = (lo + hi + 1) >> 1; const int b = cc[mid]; if (b >= 0 && b <= c) lo = mid; else hi = mid - 1; }
+			const int r = lo;
+			v = chunk_rows[(size_t)(chunk_base[k] + src_chunk[(size_t)k * KC + r]) * row_stride + c];
+		}
+		dst[c] = (uint8_t)v;
+	}
+}
+
+hipError_t launch_hazard_merge(const uint16_t* colmax16, uint8_t* colmax, const int32_t* unit_ids, int32_t nlist, const int32_t* unit_len,
+	const int32_t* chunk_cols, const int32_t* chunk_base, const int32_t* src_chunk, const int32_t* zero_from, const uint8_t* chunk_rows, int32_t row_stride, int32_t tstride, hipStream_t st)
+{
+	if (nlist <= 0) return hipSuccess;
+	hipLaunchKernelGGL(k_hazard_merge, dim3((unsigned)nlist), dim3(64), 0, st, colmax16, colmax, unit_ids, unit_len, chunk_cols, chunk_base, src_chunk, zero_from,
+		chunk_rows, row_stride, tstride);
+	return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -101,6 +101,14 @@ struct ScanArgs {
 	int32_t tile;                // this launch handles virtual lanes [128*tile, 128*tile+128)
 	int32_t ntiles;
 	uint2* boundary;             // [unit][tstride]: per column {hbot | fbot<<16, cm | fpo<<16} handed from tile to tile
+	int32_t* unit_first;         // [unit] atomicMin: first pipeline step at which a Q2 taint could arise (NULL: not tracked)
+	// DUMP variant only (checkpoints for the chunked hazard re-run): work item w dumps H and E of every row after columns
+	// dump_cols[w][0 .. HAZARD_MAX_CHUNKS) (ascending; -1 = unused) into dump_state[(dump_base[w] + k)][2][rows_total]
+	// (values as carried: 2 * value + taint)
+	const int32_t* dump_cols;
+	const int32_t* dump_base;
+	uint16_t* dump_state;
+	int32_t rows_total;          // 16 * ceil(m/16)
 };
 
 // rows owned by global virtual lane v (stripe-aligned layout): stripe s = v / vs gets its ceil(m/16) rows spread over
@@ -140,8 +148,8 @@ __device__ __forceinline__ int pair_lane_offset(int lane) { return (lane >> 3) *
 //               (16 pairs of bases + the pair (N, N), 6.4 KB each): one VALU op per row less.  A lane whose halves are
 //               (base, N) -- the front of the pipeline while it fills or drains, or a real N in the DNA -- reads the
 //               pair with A in place of N and patches the N half in (a wave-uniform branch, ~2.5 % of the steps).
-template <int RP, bool PAIR>
-__global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_scan(ScanArgs a)
+template <int RP, bool PAIR, bool DUMP = false>
+__global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves_per_eu(DUMP ? 1 : 4, DUMP ? 2 : 4))) k_scan(ScanArgs a)
 {
 	extern __shared__ __align__(16) uint8_t prof[];
 	const int lane = threadIdx.x & 63;
@@ -217,7 +225,28 @@ __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves
 		int hbot = 0, fbot = 0, cm = 0, recv_h_last = 0, fpo = 0;
 		v2u hzacc = (v2u){ 0, 0 };      // != 0: the unit goes to the stripe-faithful kernel (coarse test of short queries)
 		int chunk = CODE_N;
-		const int nsteps = n + 127;
+		int first_enter = 0x7fffffff;          // first step of this unit in which the hazard branch ran (wave-uniform)
+		// DUMP only: the reference's OWN E.  Its lazy-F loop corrects H but not E (sswNew.cpp:355: "don't update E"), so E follows
+		// the H of the main pass, which only knows the F chain restarted at the top of each stripe (Fm).  The H values are the
+		// same either way (a gap pair in the order down-right scores what right-down scores), the E array is not, and a
+		// checkpoint has to be the reference's exact state.
+		int Es[RP]; int fmbot = 0;
+#pragma unroll
+		for (int r = 0; r < RP; r++) Es[r] = 0;
+		// checkpoint columns are ascending and a half's column moves up by one per step: each half only watches its NEXT one
+		int dlast = -1, dnext[2] = { 0x7fffffff, 0x7fffffff }, dnx[2] = { 0, 0 };
+		int drow0[2] = { 0, 0 }, drows[2] = { 0, 0 };
+		const int32_t* dc = nullptr; int dbase = 0;
+		if constexpr (DUMP) {
+			dc = a.dump_cols + (size_t)w * HAZARD_MAX_CHUNKS; dbase = a.dump_base[w];
+			for (int k = 0; k < HAZARD_MAX_CHUNKS; k++) { const int c = dc[k]; dlast = c > dlast ? c : dlast; }
+			int first = 0;
+			while (first < HAZARD_MAX_CHUNKS && dc[first] < 0) first++;              // (chunk 0 of a unit that starts at column 0 has no checkpoint)
+			if (first < HAZARD_MAX_CHUNKS) { dnext[0] = dnext[1] = dc[first]; dnx[0] = dnx[1] = first; }
+			for (int h = 0; h < 2; h++) lane_rows(128 * a.tile + 2 * lane + h, a.seg_len16, a.vs, &drow0[h], &drows[h]);
+		}
+		// (the DUMP variant only has to reach its last checkpoint column)
+		const int nsteps = DUMP ? (dlast < 0 ? 0 : (dlast + 1 < n ? dlast + 1 : n) + 127) : n + 127;
 		// The step body is instantiated twice per loop iteration: within one step the new H column is written into the
 		// registers the profile rows were loaded into (the old H column is still being read), so consecutive steps
 		// alternate between two register banks; with a single copy of the body the compiler has to move the whole column
@@ -254,6 +283,8 @@ __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves
 			const int hdiag0 = recv_h_last;           // H[i0-1][c-1]
 			recv_h_last = recv_h;
 			v2u f = __builtin_bit_cast(v2u, recv_f);
+			v2u fm = (v2u){ 0, 0 };
+			if constexpr (DUMP) fm = __builtin_bit_cast(v2u, vshift0(fmbot)) & ~startm;      // the main pass starts every stripe with F = 0
 			v2s lmx[4] = { (v2s){ 0, 0 }, (v2s){ 0, 0 }, (v2s){ 0, 0 }, (v2s){ 0, 0 } };   // independent chains: no back-to-back dependent v_pk_max
 			constexpr int ROWS_PER_LOAD = PAIR ? 4 : 8;
 			constexpr int NLOAD = (RP + ROWS_PER_LOAD - 1) / ROWS_PER_LOAD;
@@ -299,6 +330,13 @@ __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves
 			for (int r = 0; r < RP; r++) {
 				v2s tnext = t;
 				if (r + 1 < RP) tnext = diag_plus_score(H[r], score_of(r + 1));
+				if constexpr (DUMP) {
+					const v2s hm = __builtin_elementwise_max(__builtin_elementwise_max(t, s_from(Es[r])), as_s(fm));
+					const v2u hom = __builtin_elementwise_sub_sat(as_u(hm), (v2u){ 2 * GAP_OPEN, 2 * GAP_OPEN });
+					Es[r] = to_int(__builtin_elementwise_max(__builtin_elementwise_sub_sat(u_fromi(Es[r]), (v2u){ 2 * GAP_EXT, 2 * GAP_EXT }), hom));
+					const v2u fmn = __builtin_elementwise_max(__builtin_elementwise_sub_sat(fm, (v2u){ 2 * GAP_EXT, 2 * GAP_EXT }), hom);
+					fm = (r == RP - 1) ? ((fmn & actm) | (fm & ~actm)) : fmn;
+				}
 				v2s h = __builtin_elementwise_max(t, s_from(E[r]));
 				// h = max(h, f), written into the register that held the OLD H[r] (tied dummy operand; its last real use was
 				// the sum for row r+1 above): the H column stays where it is from step to step
@@ -325,6 +363,7 @@ __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves
 			// next to the (possibly tainted) ones and the common path pays a register copy per row at the join
 			asm volatile("" :: "v"(to_int(lmax)));
 			fbot = to_int(f);
+			if constexpr (DUMP) fmbot = to_int(fm);
 			// ---- Q2 hazard.  The reference's lazy-F loop leaves early (signed compare, sswNew.cpp:369) only while a
 			// stripe's propagated boundary value Fp = F[b] - 4j is >= 132 and the H it has just corrected is < 144
 			// (then vF >= 128 reads as negative, vH < 128 as positive).  From then on the rows of that stripe whose H is
@@ -347,6 +386,7 @@ __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves
 					enter = __builtin_amdgcn_ballot_w64(to_int(hot) != 0) != 0ull;
 				}
 				if (enter) {
+					first_enter = first_enter < step ? first_enter : step;
 					v2u fp = fp_in, arm = arm_in;
 					const v2u one = (v2u){ 1, 1 };
 					constexpr uint32_t K1 = 0x00010001u, K263 = 263u * 0x10001u, K288 = 288u * 0x10001u, KE = (2u * GAP_EXT) * 0x10001u,
@@ -388,6 +428,28 @@ __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves
 				// F[b] >= 132 sends the unit to the stripe-faithful kernel
 				hzacc |= __builtin_elementwise_sub_sat(__builtin_bit_cast(v2u, recv_f), fthr2);
 			}
+			if constexpr (DUMP) {
+				// my lo half has just finished column step - 2*lane, my hi half column step - 2*lane - 1
+				const int col_lo = step - 2 * lane, col_hi = col_lo - 1;
+				if (__builtin_amdgcn_ballot_w64(col_lo == dnext[0] || col_hi == dnext[1]) != 0ull) {
+					if (col_lo == dnext[0]) {
+						uint16_t* sp = a.dump_state + (size_t)(dbase + dnx[0]) * 2 * a.rows_total + drow0[0];
+#pragma unroll
+						for (int r = 0; r < RP; r++) if (r < drows[0]) { sp[r] = (uint16_t)H[r]; sp[a.rows_total + r] = (uint16_t)Es[r]; }
+						dnx[0]++;
+						const int c = dnx[0] < HAZARD_MAX_CHUNKS ? dc[dnx[0]] : -1;
+						dnext[0] = c < 0 ? 0x7fffffff : c;
+					}
+					if (col_hi == dnext[1]) {
+						uint16_t* sp = a.dump_state + (size_t)(dbase + dnx[1]) * 2 * a.rows_total + drow0[1];
+#pragma unroll
+						for (int r = 0; r < RP; r++) if (r < drows[1]) { sp[r] = (uint16_t)((uint32_t)H[r] >> 16); sp[a.rows_total + r] = (uint16_t)((uint32_t)Es[r] >> 16); }
+						dnx[1]++;
+						const int c = dnx[1] < HAZARD_MAX_CHUNKS ? dc[dnx[1]] : -1;
+						dnext[1] = c < 0 ? 0x7fffffff : c;
+					}
+				}
+			}
 			cm = to_int(__builtin_elementwise_max(__builtin_bit_cast(v2u, recv_cm), as_u(lmax)));
 			const int cdone = step - 127;
 			if (lane == 63 && cdone >= 0) {
@@ -399,7 +461,25 @@ __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves
 		for (; step + 1 < nsteps; step += 2) { do_step(step); do_step(step + 1); }
 		if (step < nsteps) do_step(step);
 		if (a.unit_hz && __builtin_amdgcn_ballot_w64(to_int(hzacc) != 0) != 0ull && lane == 0) atomicOr(a.unit_hz + unit, 1);
+		if (!DUMP && a.unit_first && first_enter != 0x7fffffff && lane == 0) atomicMin(a.unit_first + unit, first_enter);
 	}
+}
+
+template <int RP>
+static hipError_t launch_scan_dump_t(const ScanArgs& a, hipStream_t st)
+{
+	hipError_t err = hipMemsetAsync(a.counter, 0, sizeof(uint32_t), st);
+	if (err != hipSuccess) return err;
+	const long blocks = ((long)a.nwork + 3) / 4;              // one unit per wave
+	// The LDS request is padded past half a CU's 160 KB so that a CU takes ONE workgroup and each of its four waves a SIMD of
+	// its own: left to itself the dispatcher packs these small workgroups onto a few CUs, and a wave that shares its SIMD's
+	// issue slot with three others takes three times as long -- this pass is on the critical path of its batch.
+	static const bool spread = [] { const char* e = getenv("FASIM_HAZARD_SPREAD"); return e ? atoi(e) != 0 : true; }();
+	const int lds = spread ? 84 * 1024 : 5 * SCAN_CODE_STRIDE;
+	static bool attr_set = false;                   // (benign race: the call is idempotent)
+	if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_scan<RP, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024); attr_set = true; }
+	hipLaunchKernelGGL((k_scan<RP, false, true>), dim3((unsigned)blocks), dim3(256), (size_t)lds, st, a);
+	return hipGetLastError();
 }
 
 template <int RP, bool PAIR>
@@ -441,6 +521,7 @@ hipError_t launch_scan(const ScanLaunch& L, hipStream_t st)
 	for (int i = 0; i < 25; i++) a.score[i] = L.score[i];
 	a.colmax16 = L.colmax16; a.unit_hz = L.unit_hz; a.coarse = L.coarse;
 	a.vs = systolic_vs(L.m); a.ntiles = a.vs / 8; a.boundary = L.boundary;
+	a.unit_first = L.unit_first; a.dump_cols = L.dump_cols; a.dump_base = L.dump_base; a.dump_state = L.dump_state; a.rows_total = 16 * a.seg_len16;
 	if (a.ntiles > 1 && !a.boundary) return hipErrorInvalidValue;
 	// RP must be exactly ceil(segLen/vs): every virtual lane then owns RP or RP-1 rows.  One launch per tile of 128
 	// virtual lanes (long queries): tile t reads the bottom row tile t-1 left in `boundary` and overwrites it in place.
@@ -450,7 +531,7 @@ hipError_t launch_scan(const ScanLaunch& L, hipStream_t st)
 		a.tile = t;
 		hipError_t err = hipErrorInvalidValue;
 		switch (rp) {
-#define FASIM_SCAN_CASE(N) case N: err = pair ? launch_scan_t<N, true>(a, st) : launch_scan_t<N, false>(a, st); break;
+#define FASIM_SCAN_CASE(N) case N: err = L.dump_cols ? launch_scan_dump_t<N>(a, st) : (pair ? launch_scan_t<N, true>(a, st) : launch_scan_t<N, false>(a, st)); break;
 		FASIM_SCAN_CASE(1) FASIM_SCAN_CASE(2) FASIM_SCAN_CASE(3) FASIM_SCAN_CASE(4) FASIM_SCAN_CASE(5) FASIM_SCAN_CASE(6)
 		FASIM_SCAN_CASE(7) FASIM_SCAN_CASE(8) FASIM_SCAN_CASE(9) FASIM_SCAN_CASE(10) FASIM_SCAN_CASE(11) FASIM_SCAN_CASE(12)
 		FASIM_SCAN_CASE(13) FASIM_SCAN_CASE(14) FASIM_SCAN_CASE(15) FASIM_SCAN_CASE(16) FASIM_SCAN_CASE(17) FASIM_SCAN_CASE(18)
