@@ -364,6 +364,9 @@ def main():
             "units": iso["units"], "align_calls": iso["align_calls"], "hazard_units": iso["hazard_units"], "rev_exact": iso["rev_exact"],
             "ms": {KERNEL_NAMES[i]: round(ik[i], 2) for i in range(7)},
             "dominant_kernel_ms_per_step_equivalent": round(ik[0] * units_per_step / max(1, iso["units"]), 1),
+            # plan + checkpoint pass + all chunks of the stripe-faithful re-run (kernel family 1), scaled to one batch of 1024 segments
+            "hazard_reruns_ms_per_49152_units": round(ik[1] * 49152 / max(1, iso["units"]), 2),
+            "hazard_launches": int(il[1]),
         }
         if not args.no_cpu_baseline and world == 1:       # the CPU baseline is reported at N = 1 only
             cores = args.cpu_cores if args.cpu_cores > 0 else host_cores()

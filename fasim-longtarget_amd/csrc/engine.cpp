@@ -73,11 +73,12 @@ struct fasim_engine {
 	std::string err;
 	std::string rna;
 	int m = 0;
+	int snap_units = 0, snap_per_unit = 0;      // pipeline snapshots of the last main scan pass (units covered, snapshots per unit)
 	ScoreLut lut1, lut2;
 	DevBuf q1, q2, enc_lut, counter, dna, seg_start, seg_len, enc_ids, tcodes, colmax, probs, max_out, unit_len,
 		stage1, hits, hits_total, hit_off, hit_cnt, thr, ends, bprobs, bout, scratch, colmax16, unit_ids, flags, stage1_in, hits2,
 		fprobs, ftasks, fstream, fout, aout, cigpool, cigcount, forder, scratch2, boundary, fboundary, unit_hz,
-		unit_first, hz_cols, hz_plan, hz_base, hz_state, hz_rows, hz_chunk, hz_src, hz_zero,   // chunked hazard re-run
+		unit_first, hz_cols, hz_plan, hz_base, hz_items, snap, hz_state, hz_rows, hz_chunk, hz_src, hz_zero,   // chunked hazard re-run
 		qsim, sim_min, sim_row, sim_ev, sim_cnt;      // -F: query codes of the SIM alphabet, thresholds, strip row buffer, events, counters
 	bool align_v1 = false;        // FASIM_ALIGN_V1=1: force the stripe-faithful kernels for stage 3
 	std::vector<fasim_engine*> workers;   // extra engines on the same device: batches in flight concurrently
@@ -91,7 +92,7 @@ struct fasim_engine {
 	int host_threads_total = 1;
 	int opt_workers = 0, opt_seg_batch = 0;      // fasim_set_option overrides (0 = default / environment)
 	int opt_taper = -1, opt_gate = -1;           // (-1 = default / environment)
-	int opt_tail_split = 0, opt_tail_items = -1; // cooperative tail: sub-tasks per batch (0 = default 4), batches at the end whose stage 3 is shared (-1 = default: one per worker)
+	int opt_tail_split = 0, opt_tail_items = -1; // cooperative tail: sub-tasks per batch (0 = default 4), batches at the end whose stage 3 is shared (-1 = default: none)
 	bool query_acgt = true;       // query holds only A,C,G,T: stage-1 and stage-2 scoring coincide on N-free segments
 	bool scan_v1 = false;         // FASIM_SCAN_V1=1: force the stripe-faithful kernels for stages 1 and 2
 	int host_threads = 1;
@@ -298,6 +299,11 @@ struct GateScope {
 	~GateScope() { release(); }
 };
 
+// FASIM_HAZARD_CHUNKS=0: whole-unit re-run of the hazard units (the round-1 path); FASIM_HAZARD_SNAP=0: the checkpoint pass
+// runs every hazard unit from column 0 instead of from the main pass's pipeline snapshots (both for measurements)
+static bool hazard_chunks_enabled() { static const bool v = [] { const char* e = getenv("FASIM_HAZARD_CHUNKS"); return e ? atoi(e) != 0 : true; }(); return v; }
+static bool hazard_snapshots_enabled() { static const bool v = [] { const char* e = getenv("FASIM_HAZARD_SNAP"); return e ? atoi(e) != 0 : true; }(); return v; }
+
 // Stripe-faithful re-run of the hazard units (Q2), cut into column chunks that run in PARALLEL (kernels.hip, "chunked hazard
 // re-run"; scan.hip, DUMP variant).
 //   * Columns before the first step at which k_scan saw a possible taint are exact already: the re-run starts there.
@@ -321,10 +327,10 @@ int run_hazard_chunked(fasim_engine* E, const UnitBatch& B, const std::vector<in
 	const int nh = (int)hz.size();
 	const int rows_total = 16 * ((E->m + 15) / 16);
 	const bool dbg = getenv("FASIM_DEBUG_HAZARD") != nullptr;
-	static const int target = [] { const char* e = getenv("FASIM_HAZARD_CHUNK_COLS"); const int v = e ? atoi(e) : 320; return v < 64 ? 64 : v; }();
+	static const int target = [] { const char* e = getenv("FASIM_HAZARD_CHUNK_COLS"); const int v = e ? atoi(e) : 200; return v < 64 ? 64 : v; }();
 	static const int hot_thr = [] { const char* e = getenv("FASIM_HAZARD_HOT_THR"); return e ? atoi(e) : 144; }();
-	static const int hot_w = [] { const char* e = getenv("FASIM_HAZARD_HOT_W"); const int v = e ? atoi(e) : 20; return v < 1 ? 1 : (v > 32 ? 32 : v); }();
-	static const bool spread = [] { const char* e = getenv("FASIM_HAZARD_SPREAD"); return e ? atoi(e) != 0 : true; }();
+	static const int hot_w = [] { const char* e = getenv("FASIM_HAZARD_HOT_W"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 32 ? 32 : v); }();
+	static const bool spread = [] { const char* e = getenv("FASIM_HAZARD_SPREAD"); return e ? atoi(e) != 0 : false; }();      // (measured: no gain alone, and 84 KB of LDS cannot start beside four k_scan workgroups)
 	auto now = [] { return std::chrono::steady_clock::now(); };
 	auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
 	const auto t_begin = now();
@@ -333,9 +339,8 @@ int run_hazard_chunked(fasim_engine* E, const UnitBatch& B, const std::vector<in
 	std::vector<int32_t> ids(hz.begin(), hz.end());
 	int rc = upload(E, E->unit_ids, ids.data(), sizeof(int32_t) * nh); if (rc) return rc;
 	HIPOK(E->hz_plan.ensure(sizeof(int32_t) * (size_t)nh * (KC + 1)));
-	HIPOK(E->hz_cols.ensure(sizeof(int32_t) * (size_t)nh * KC));
 	hipError_t he = launch_hazard_plan(E->unit_ids.as<int32_t>(), nh, E->unit_len.as<int32_t>(), E->unit_first.as<int32_t>(), E->colmax16.as<uint16_t>(),
-		B.tstride, target, hot_thr, hot_w, E->hz_plan.as<int32_t>(), E->hz_cols.as<int32_t>(), E->st);
+		B.tstride, target, hot_thr, hot_w, E->hz_plan.as<int32_t>(), E->st);
 	if (he != hipSuccess) return fail(E, FASIM_E_HIP, "hazard plan launch failed: %s", hipGetErrorString(he));
 	std::vector<int32_t> plan((size_t)nh * (KC + 1));
 	HIPOK(hipMemcpyAsync(plan.data(), E->hz_plan.p, sizeof(int32_t) * plan.size(), hipMemcpyDeviceToHost, E->st));
@@ -362,14 +367,57 @@ int run_hazard_chunked(fasim_engine* E, const UnitBatch& B, const std::vector<in
 	const int np = (int)probs.size();
 	rc = upload(E, E->hz_base, base.data(), sizeof(int32_t) * nh); if (rc) return rc;
 
-	// 2. checkpoint pass
+	// 2. checkpoint pass: the state chunk j starts from = the state after column c[j] - 1.  One work item per window of
+	// SCAN_SNAP_STEPS columns that holds such a column: it continues from the pipeline snapshot the main pass left at the
+	// window's first step (columns less than 64 past a snapshot belong to the window before: see scan.hip)
+	std::vector<int32_t> cols((size_t)np, -1);
+	std::vector<ScanDumpItem> items;
+	const bool windows = E->snap_units >= B.nunit && E->snap_per_unit > 0;
+	for (int k = 0; k < nh; k++) {
+		const int32_t* c = &plan[(size_t)k * (KC + 1)];
+		int cur = -1;
+		for (int j = 0; j < nchunk[(size_t)k]; j++) {
+			const int X = c[j] - 1;
+			if (X < 0) continue;                                   // (chunk 0 of a unit that starts at column 0: the zero state)
+			cols[(size_t)base[(size_t)k] + j] = X;
+			int win = (!windows || X < SCAN_SNAP_STEPS + 64) ? 0 : (X - 64) / SCAN_SNAP_STEPS;
+			if (win > E->snap_per_unit) win = E->snap_per_unit;
+			if (win != cur) { items.push_back({ hz[(size_t)k], win * SCAN_SNAP_STEPS, base[(size_t)k] + j, 0 }); cur = win; }
+			items.back().count++;
+		}
+	}
 	HIPOK(E->hz_state.ensure((size_t)np * 2 * rows_total * sizeof(uint16_t)));
-	{
+	if (!items.empty()) {
+		rc = upload(E, E->hz_cols, cols.data(), sizeof(int32_t) * np); if (rc) return rc;
+		rc = upload(E, E->hz_items, items.data(), sizeof(ScanDumpItem) * items.size()); if (rc) return rc;
 		ScanLaunch L = Lmain;
-		L.unit_ids = E->unit_ids.as<int32_t>(); L.nwork = nh; L.unit_hz = nullptr; L.unit_first = nullptr;
-		L.dump_cols = E->hz_cols.as<int32_t>(); L.dump_base = E->hz_base.as<int32_t>(); L.dump_state = E->hz_state.as<uint16_t>();
+		L.unit_ids = nullptr; L.nwork = (int)items.size(); L.unit_hz = nullptr; L.unit_first = nullptr;
+		L.snap = windows ? E->snap.as<uint32_t>() : nullptr; L.snap_per_unit = windows ? E->snap_per_unit : 0;
+		L.dump_items = E->hz_items.as<ScanDumpItem>(); L.dump_cols = E->hz_cols.as<int32_t>(); L.dump_state = E->hz_state.as<uint16_t>();
 		{ TimedScope ts(E, 1); he = launch_scan(L, E->st); }
 		if (he != hipSuccess) return fail(E, FASIM_E_HIP, "scan (checkpoint pass) launch failed: %s", hipGetErrorString(he));
+		if (dbg && atoi(getenv("FASIM_DEBUG_HAZARD")) >= 2 && windows) {
+			// self-check of the windowed pass: the same checkpoints from a pass that starts every unit at column 0
+			const size_t bytes = (size_t)np * 2 * rows_total * sizeof(uint16_t);
+			std::vector<uint16_t> got(bytes / 2), want(bytes / 2);
+			HIPOK(hipMemcpyAsync(got.data(), E->hz_state.p, bytes, hipMemcpyDeviceToHost, E->st));
+			HIPOK(hipStreamSynchronize(E->st));
+			std::vector<ScanDumpItem> whole;
+			for (const ScanDumpItem& it : items) { if (!whole.empty() && whole.back().unit == it.unit) whole.back().count += it.count; else whole.push_back({ it.unit, 0, it.first, it.count }); }
+			rc = upload(E, E->hz_items, whole.data(), sizeof(ScanDumpItem) * whole.size()); if (rc) return rc;
+			L.nwork = (int)whole.size(); L.snap = nullptr; L.snap_per_unit = 0;
+			he = launch_scan(L, E->st);
+			if (he != hipSuccess) return fail(E, FASIM_E_HIP, "scan (checkpoint self-check) launch failed: %s", hipGetErrorString(he));
+			HIPOK(hipMemcpyAsync(want.data(), E->hz_state.p, bytes, hipMemcpyDeviceToHost, E->st));
+			HIPOK(hipStreamSynchronize(E->st));
+			size_t bad = 0, checked = 0;
+			for (int x = 0; x < np; x++) {
+				if (cols[(size_t)x] < 0) continue;
+				for (int r = 0; r < 2 * rows_total; r++) { checked++; if ((got[(size_t)x * 2 * rows_total + r] >> 1) != (want[(size_t)x * 2 * rows_total + r] >> 1)) bad++; }
+			}
+			fprintf(stderr, "[hazard] checkpoint self-check: %zu of %zu values differ between the windowed and the whole pass (%zu items vs %zu)\n", bad, checked, items.size(), whole.size());
+			if (bad) return fail(E, FASIM_E_HIP, "hazard re-run: windowed checkpoint pass disagrees with the whole pass");
+		}
 	}
 	if (dbg) { HIPOK(hipStreamSynchronize(E->st)); fprintf(stderr, "[hazard] %d units, %d chunks; plan + checkpoint pass done at %.2f ms\n", nh, np, ms_since(t_begin)); }
 
@@ -472,6 +520,15 @@ int run_scan_v2(fasim_engine* E, const UnitBatch& B, const std::vector<char>& un
 	HIPOK(E->unit_first.ensure(sizeof(int32_t) * nu));
 	HIPOK(hipMemsetAsync(E->unit_first.p, 0x7f, sizeof(int32_t) * nu, E->st));      // 0x7f7f7f7f = "no taint arose"
 	L.unit_first = E->unit_first.as<int32_t>();
+	// pipeline snapshots for the chunked hazard re-run (single-tile queries): [unit][snapshot][dwords][64 lanes]
+	E->snap_units = 0; E->snap_per_unit = 0;
+	if (hazard_chunks_enabled() && systolic_fits(E->m) && systolic_tiles(E->m) == 1 && hazard_snapshots_enabled()) {
+		const int spu = (B.tstride + 127) / SCAN_SNAP_STEPS;
+		if (spu > 0) {
+			HIPOK(E->snap.ensure((size_t)nu * spu * systolic_snap_dwords(E->m) * 64 * sizeof(uint32_t)));
+			L.snap = E->snap.as<uint32_t>(); L.snap_per_unit = spu; E->snap_units = nu; E->snap_per_unit = spu;
+		}
+	}
 	if (E->st_heavy != E->st) HIPOK(hipStreamSynchronize(E->st));      // k_encode and the memset above ran on the other stream
 	{
 		GateScope gate(E);
@@ -534,7 +591,7 @@ int run_scan_v2(fasim_engine* E, const UnitBatch& B, const std::vector<char>& un
 		if (st) st->hazard_units += (int64_t)hz.size();
 		HIPOK(E->colmax.ensure((size_t)nu * B.tstride));
 		HIPOK(E->max_out.ensure(sizeof(int32_t) * nu));
-		static const bool chunked = [] { const char* e = getenv("FASIM_HAZARD_CHUNKS"); return e ? atoi(e) != 0 : true; }();
+		const bool chunked = hazard_chunks_enabled();
 		// (a query of more than one tile of 128 virtual lanes, > 3 072 nt, keeps the whole-unit re-run: the checkpoint pass does not
 		//  hand the restarted F chain from tile to tile)
 		if (chunked && systolic_tiles(E->m) == 1) { rc = run_hazard_chunked(E, B, hz, L); if (rc) return rc; }
@@ -1049,7 +1106,7 @@ void fasim_engine_destroy(fasim_engine* e)
 		&e->colmax, &e->probs, &e->max_out, &e->unit_len, &e->stage1, &e->hits, &e->hits_total, &e->hit_off, &e->hit_cnt, &e->thr,
 		&e->ends, &e->bprobs, &e->bout, &e->scratch, &e->dna_res, &e->colmax16, &e->unit_ids, &e->flags, &e->stage1_in, &e->hits2,
 		&e->fprobs, &e->ftasks, &e->fstream, &e->fout, &e->aout, &e->cigpool, &e->cigcount, &e->forder, &e->scratch2, &e->boundary, &e->fboundary, &e->unit_hz,
-		&e->unit_first, &e->hz_cols, &e->hz_plan, &e->hz_base, &e->hz_state, &e->hz_rows, &e->hz_chunk, &e->hz_src, &e->hz_zero,
+		&e->unit_first, &e->hz_cols, &e->hz_plan, &e->hz_base, &e->hz_items, &e->snap, &e->hz_state, &e->hz_rows, &e->hz_chunk, &e->hz_src, &e->hz_zero,
 		&e->qsim, &e->sim_min, &e->sim_row, &e->sim_ev, &e->sim_cnt };
 	for (auto& t : e->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
 	for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
@@ -1982,10 +2039,12 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 		// stage 3 of the LAST `tail_items` items is published as `tail_split` sub-tasks (unit ranges), which the owner and
 		// every worker that has run out of items work off together, so the end of a scan is not one batch's sequential rounds
 		// on an otherwise idle GPU.  Earlier items run their stage 3 as one piece on the owner (fewer, larger launches).
+		// OFF by default (tail_items 0): against the tree before this change, on the same box, it loses 0.1 s per 50 Mb scan (the
+		// split launches are less efficient than the idle time they fill: profiles/r02_ab_trees.txt).
 		static const int env_split = [] { const char* e = getenv("FASIM_TAIL_SPLIT"); return e ? atoi(e) : 4; }();
 		static const int env_tail = [] { const char* e = getenv("FASIM_TAIL_ITEMS"); return e ? atoi(e) : -1; }();
 		const int tail_split = std::max(1, E->opt_tail_split > 0 ? E->opt_tail_split : env_split);
-		const size_t tail_items = (size_t)std::max(0, E->opt_tail_items >= 0 ? E->opt_tail_items : (env_tail >= 0 ? env_tail : nworkers));
+		const size_t tail_items = (size_t)std::max(0, E->opt_tail_items >= 0 ? E->opt_tail_items : (env_tail >= 0 ? env_tail : 0));
 		struct SubTask { size_t item; int ua, ub; };
 		struct BatchRun { BatchCtx ctx; std::atomic<int> pending{ 0 }; std::mutex mu; fasim_scan_stats st3; int rc = FASIM_OK; };
 		std::vector<std::unique_ptr<BatchRun>> runs(items.size());

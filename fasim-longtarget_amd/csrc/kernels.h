@@ -43,7 +43,7 @@ hipError_t launch_hits(const uint8_t* colmax, const int32_t* unit_ids, const int
 
 // chunked hazard re-run (kernels.hip): chunk plan of every hazard unit, and the merge of the groups' private rows
 hipError_t launch_hazard_plan(const int32_t* unit_ids, int32_t nlist, const int32_t* unit_len, const int32_t* unit_first, const uint16_t* colmax16,
-	int32_t tstride, int32_t target, int32_t hot_thr, int32_t hot_w, int32_t* chunk_cols, int32_t* dump_cols, hipStream_t st);
+	int32_t tstride, int32_t target, int32_t hot_thr, int32_t hot_w, int32_t* chunk_cols, hipStream_t st);
 hipError_t launch_hazard_merge(const uint16_t* colmax16, uint8_t* colmax, const int32_t* unit_ids, int32_t nlist, const int32_t* unit_len,
 	const int32_t* chunk_cols, const int32_t* chunk_base, const int32_t* src_chunk, const int32_t* zero_from, const uint8_t* chunk_rows, int32_t row_stride, int32_t tstride, hipStream_t st);
 
@@ -51,6 +51,10 @@ hipError_t launch_banded(const uint8_t* tcodes, const uint8_t* qcodes, const Ban
 	uint8_t* scratch, BandOut* out, hipStream_t st);
 
 // ---- scan.hip: fused stage-1 + stage-2 systolic kernel ---------------------------------------------
+constexpr int SCAN_SNAP_STEPS = 1024;
+// one work item of the checkpoint pass: continue unit `unit` from pipeline step `step0` (0, or a multiple of SCAN_SNAP_STEPS:
+// from the snapshot taken there) and leave the DP state after columns dump_cols[first .. first + count)
+struct ScanDumpItem { int32_t unit, step0, first, count; };
 struct ScanLaunch {
 	const uint8_t* tcodes; const int32_t* unit_ids; const int32_t* unit_len; int32_t nwork; int32_t tstride;
 	uint32_t* counter; const uint8_t* qcodes; int32_t m; int8_t score[25]; uint16_t* colmax16;
@@ -58,13 +62,19 @@ struct ScanLaunch {
 	int32_t coarse;       // 1: coarse Q2 test (FASIM_Q2_COARSE=1, for measurements)
 	int32_t* unit_hz;     // [unit], zeroed by the caller: |= 1 when the unit needs the stripe-faithful re-run; may be NULL
 	int32_t* unit_first = nullptr;          // [unit], preset to INT_MAX by the caller: first step at which a Q2 taint could arise
-	const int32_t* dump_cols = nullptr;     // != NULL: checkpoint variant: [nwork][HAZARD_MAX_CHUNKS] columns after which H / E of all rows are dumped
-	const int32_t* dump_base = nullptr;   // [work item]: index of its first checkpoint in dump_state
-	uint16_t* dump_state = nullptr;         // [nwork * 8][2][16 * ceil(m/16)]
+	// pipeline snapshots: the main pass leaves its whole wave state every SCAN_SNAP_STEPS steps, so that the checkpoint pass of
+	// the chunked hazard re-run can start in the middle of a unit (single-tile queries only)
+	uint32_t* snap = nullptr;               // [unit][snap_per_unit][systolic_snap_dwords(m)][64 lanes]; NULL: none taken / none to read
+	int32_t snap_per_unit = 0;
+	// checkpoint variant (dump_items != NULL): work item = one window of one hazard unit
+	const ScanDumpItem* dump_items = nullptr;
+	const int32_t* dump_cols = nullptr;     // [chunk]: the column after which the DP state of all rows is wanted (ascending within an item)
+	uint16_t* dump_state = nullptr;         // [chunk][2][16 * ceil(m/16)]: H, then the reference's E
 };
 int systolic_vs(int m);
 int systolic_tiles(int m);     // query tiles of 128 virtual lanes x <= 24 rows (1 for m <= 3072)
 bool systolic_fits(int m);
+int systolic_snap_dwords(int m); // dwords per lane of one pipeline snapshot
 hipError_t launch_scan(const ScanLaunch& L, hipStream_t st);      // hipErrorInvalidValue: query too long for this kernel
 hipError_t launch_scan_post(const uint16_t* colmax16, const int32_t* unit_ids, int32_t nwork, const int32_t* unit_len,
 	int32_t tstride, const int32_t* stage1_in, uint32_t* hits, uint32_t hits_cap, uint32_t* hits_total, int32_t* hit_off,

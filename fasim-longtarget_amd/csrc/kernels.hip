@@ -166,7 +166,11 @@ __device__ __forceinline__ int column_byte(uint8_t* Hs, uint8_t* Es, const uint8
 			const int ho = max(h - GAP_OPEN, 0);
 			f = max(f - GAP_EXT, 0);
 			const bool c = QUIRK ? ((int)(int8_t)f > (int)(int8_t)ho) : (f > ho);
-			if (!group_any16(c)) { go = false; break; }
+			// The reference leaves the loop when no lane has vF > vH - gapO (signed compare: Q2).  With H - gapO >= 128 that
+			// compare stays true even for F = 0, and the reference then grinds through all 16 * segLen iterations -- which change
+			// nothing once every lane's F has decayed to 0 (h = max(h, 0), F stays 0 through the shifts).  Leaving at that point
+			// gives the same H column and the same maximum.
+			if (!group_any16(c) || !group_any16(f > 0)) { go = false; break; }
 		}
 	}
 	return cmax;
@@ -466,11 +470,10 @@ hipError_t launch_striped(StripedMode mode, bool word, bool quirk, const Striped
 //   * [f, n) is cut into K <= HAZARD_MAX_CHUNKS chunks of about equal COST.  A column whose maximum reaches `hot_thr` is
 //     priced `hot_w` times a plain one: there the reference's lazy-F loop keeps running (H - gapO >= 128 reads as negative
 //     in its signed compare, sswNew.cpp:369), and so does the emulation.
-// chunk_cols[k][0 .. K] = chunk boundaries (c[0] = f, c[K] = n, -1 beyond); dump_cols[k][j] = c[j] - 1 = the column after
-// which the checkpoint pass (k_scan<.., DUMP>) leaves the DP state chunk j starts from (-1: none).
+// chunk_cols[k][0 .. K] = chunk boundaries (c[0] = f, c[K] = n, -1 beyond).
 __global__ void __launch_bounds__(64) k_hazard_plan(const int32_t* __restrict__ unit_ids, const int32_t* __restrict__ unit_len,
 	const int32_t* __restrict__ unit_first, const uint16_t* __restrict__ colmax16, int32_t tstride, int32_t target, int32_t hot_thr, int32_t hot_w,
-	int32_t* __restrict__ chunk_cols, int32_t* __restrict__ dump_cols)
+	int32_t* __restrict__ chunk_cols)
 {
 	constexpr int KC = HAZARD_MAX_CHUNKS;
 	const int k = blockIdx.x, lane = threadIdx.x, unit = unit_ids[k], n = unit_len[unit];
@@ -487,27 +490,26 @@ __global__ void __launch_bounds__(64) k_hazard_plan(const int32_t* __restrict__ 
 	const int W = max(1, __shfl(incl, 63, 64));
 	const int K = max(1, min(KC, (W + target - 1) / target));
 	int32_t* cc = chunk_cols + (size_t)k * (KC + 1);
-	int32_t* dc = dump_cols + (size_t)k * KC;
-	if (lane == 0) { cc[0] = f; dc[0] = f - 1; }
-	for (int j = K + lane; j <= KC; j += 64) { cc[j] = j == K ? n : -1; if (j < KC) dc[j] = -1; }
+	if (lane == 0) cc[0] = f;
+	for (int j = K + lane; j <= KC; j += 64) cc[j] = j == K ? n : -1;
 	// boundary q = the first column whose exclusive cost prefix p satisfies floor(p * K / W) >= q  (W / K > hot_w: the quotient
 	// moves by at most one per column)
 	int p = incl - wsum;
 	int qlast = (c0 > f && c0 < n) ? (int)(((int64_t)(p - weight(c0 - 1)) * K) / W) : 0;
 	for (int c = c0; c < c1; c++) {
 		const int q = (int)(((int64_t)p * K) / W);
-		if (q > qlast && q < K) { cc[q] = c; dc[q] = c - 1; }
+		if (q > qlast && q < K) cc[q] = c;
 		qlast = q;
 		p += weight(c);
 	}
 }
 
 hipError_t launch_hazard_plan(const int32_t* unit_ids, int32_t nlist, const int32_t* unit_len, const int32_t* unit_first, const uint16_t* colmax16,
-	int32_t tstride, int32_t target, int32_t hot_thr, int32_t hot_w, int32_t* chunk_cols, int32_t* dump_cols, hipStream_t st)
+	int32_t tstride, int32_t target, int32_t hot_thr, int32_t hot_w, int32_t* chunk_cols, hipStream_t st)
 {
 	if (nlist <= 0) return hipSuccess;
 	hipLaunchKernelGGL(k_hazard_plan, dim3((unsigned)nlist), dim3(64), 0, st, unit_ids, unit_len, unit_first, colmax16, tstride, target, hot_thr, hot_w,
-		chunk_cols, dump_cols);
+		chunk_cols);
 	return hipGetLastError();
 }
 

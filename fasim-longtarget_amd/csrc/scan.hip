@@ -102,11 +102,13 @@ struct ScanArgs {
 	int32_t ntiles;
 	uint2* boundary;             // [unit][tstride]: per column {hbot | fbot<<16, cm | fpo<<16} handed from tile to tile
 	int32_t* unit_first;         // [unit] atomicMin: first pipeline step at which a Q2 taint could arise (NULL: not tracked)
-	// DUMP variant only (checkpoints for the chunked hazard re-run): work item w dumps H and E of every row after columns
-	// dump_cols[w][0 .. HAZARD_MAX_CHUNKS) (ascending; -1 = unused) into dump_state[(dump_base[w] + k)][2][rows_total]
-	// (values as carried: 2 * value + taint)
+	uint32_t* snap;              // pipeline snapshots [unit][snap_per_unit][2 * RP + 6][64] (main pass: written; DUMP: read); may be NULL
+	int32_t snap_per_unit;
+	// DUMP variant only (checkpoints for the chunked hazard re-run): work item w = dump_items[w] continues a unit from a
+	// snapshot (or from step 0) and leaves H and the reference's E of every row after columns dump_cols[first .. first + count)
+	// in dump_state[chunk][2][rows_total] (values as carried: 2 * value + taint)
+	const ScanDumpItem* dump_items;
 	const int32_t* dump_cols;
-	const int32_t* dump_base;
 	uint16_t* dump_state;
 	int32_t rows_total;          // 16 * ceil(m/16)
 };
@@ -208,7 +210,9 @@ __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves
 		if (lane == 0) w = (int)atomicAdd(a.counter, 1u);
 		w = __builtin_amdgcn_readfirstlane(w);
 		if (w >= a.nwork) break;
-		const int unit = a.unit_ids[w];
+		ScanDumpItem item = { 0, 0, 0, 0 };
+		if constexpr (DUMP) item = a.dump_items[w];
+		const int unit = DUMP ? item.unit : a.unit_ids[w];
 		const int n = a.unit_len[unit];
 		const uint8_t* tc_unit = a.tcodes + (int64_t)unit * a.tstride;
 		uint16_t* out = a.colmax16 + (int64_t)unit * a.tstride;
@@ -236,14 +240,22 @@ __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves
 		// checkpoint columns are ascending and a half's column moves up by one per step: each half only watches its NEXT one
 		int dlast = -1, dnext[2] = { 0x7fffffff, 0x7fffffff }, dnx[2] = { 0, 0 };
 		int drow0[2] = { 0, 0 }, drows[2] = { 0, 0 };
-		const int32_t* dc = nullptr; int dbase = 0;
+		const int32_t* dc = nullptr;
+		constexpr int SNAP_DW = 2 * RP + 6;
 		if constexpr (DUMP) {
-			dc = a.dump_cols + (size_t)w * HAZARD_MAX_CHUNKS; dbase = a.dump_base[w];
-			for (int k = 0; k < HAZARD_MAX_CHUNKS; k++) { const int c = dc[k]; dlast = c > dlast ? c : dlast; }
-			int first = 0;
-			while (first < HAZARD_MAX_CHUNKS && dc[first] < 0) first++;              // (chunk 0 of a unit that starts at column 0 has no checkpoint)
-			if (first < HAZARD_MAX_CHUNKS) { dnext[0] = dnext[1] = dc[first]; dnx[0] = dnx[1] = first; }
+			dc = a.dump_cols + item.first;
+			if (item.count > 0) { dlast = dc[item.count - 1]; dnext[0] = dnext[1] = dc[0]; }
 			for (int h = 0; h < 2; h++) lane_rows(128 * a.tile + 2 * lane + h, a.seg_len16, a.vs, &drow0[h], &drows[h]);
+			if (item.step0 > 0) {
+				// continue from the snapshot the main pass took at the top of step step0.  The reference's E starts as the textbook
+				// E and is exact 64 columns later (a surplus decays by the gap extension, 4 a column, from at most 250; the
+				// restarted F chain follows within the column): the host only asks for columns >= step0 + 64 here.
+				const uint32_t* sp = a.snap + ((size_t)unit * a.snap_per_unit + (item.step0 / SCAN_SNAP_STEPS - 1)) * (SNAP_DW * 64) + lane;
+#pragma unroll
+				for (int r = 0; r < RP; r++) { H[r] = (int)sp[(2 * r) * 64]; E[r] = (int)sp[(2 * r + 1) * 64]; Es[r] = E[r]; }
+				tc = (int)sp[(2 * RP) * 64]; hbot = (int)sp[(2 * RP + 1) * 64]; fbot = (int)sp[(2 * RP + 2) * 64]; cm = (int)sp[(2 * RP + 3) * 64];
+				recv_h_last = (int)sp[(2 * RP + 4) * 64]; fpo = (int)sp[(2 * RP + 5) * 64];
+			}
 		}
 		// (the DUMP variant only has to reach its last checkpoint column)
 		const int nsteps = DUMP ? (dlast < 0 ? 0 : (dlast + 1 < n ? dlast + 1 : n) + 127) : n + 127;
@@ -433,20 +445,18 @@ __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves
 				const int col_lo = step - 2 * lane, col_hi = col_lo - 1;
 				if (__builtin_amdgcn_ballot_w64(col_lo == dnext[0] || col_hi == dnext[1]) != 0ull) {
 					if (col_lo == dnext[0]) {
-						uint16_t* sp = a.dump_state + (size_t)(dbase + dnx[0]) * 2 * a.rows_total + drow0[0];
+						uint16_t* sp = a.dump_state + (size_t)(item.first + dnx[0]) * 2 * a.rows_total + drow0[0];
 #pragma unroll
 						for (int r = 0; r < RP; r++) if (r < drows[0]) { sp[r] = (uint16_t)H[r]; sp[a.rows_total + r] = (uint16_t)Es[r]; }
 						dnx[0]++;
-						const int c = dnx[0] < HAZARD_MAX_CHUNKS ? dc[dnx[0]] : -1;
-						dnext[0] = c < 0 ? 0x7fffffff : c;
+						dnext[0] = dnx[0] < item.count ? dc[dnx[0]] : 0x7fffffff;
 					}
 					if (col_hi == dnext[1]) {
-						uint16_t* sp = a.dump_state + (size_t)(dbase + dnx[1]) * 2 * a.rows_total + drow0[1];
+						uint16_t* sp = a.dump_state + (size_t)(item.first + dnx[1]) * 2 * a.rows_total + drow0[1];
 #pragma unroll
 						for (int r = 0; r < RP; r++) if (r < drows[1]) { sp[r] = (uint16_t)((uint32_t)H[r] >> 16); sp[a.rows_total + r] = (uint16_t)((uint32_t)Es[r] >> 16); }
 						dnx[1]++;
-						const int c = dnx[1] < HAZARD_MAX_CHUNKS ? dc[dnx[1]] : -1;
-						dnext[1] = c < 0 ? 0x7fffffff : c;
+						dnext[1] = dnx[1] < item.count ? dc[dnx[1]] : 0x7fffffff;
 					}
 				}
 			}
@@ -457,8 +467,20 @@ __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves
 				else bnd[cdone] = make_uint2(((uint32_t)hbot >> 16) | ((uint32_t)fbot & 0xffff0000u), ((uint32_t)cm >> 16) | ((uint32_t)fpo & 0xffff0000u));
 			}
 		};
-		int step = 0;
-		for (; step + 1 < nsteps; step += 2) { do_step(step); do_step(step + 1); }
+		int step = DUMP ? item.step0 : 0;
+		for (; step + 1 < nsteps; step += 2) {
+			if constexpr (!DUMP && !PAIR) {
+				// pipeline snapshot (every SCAN_SNAP_STEPS steps, all lanes at once: ~50 stores per 1024 steps of ~230 instructions)
+				if (a.snap && step != 0 && (step & (SCAN_SNAP_STEPS - 1)) == 0 && step / SCAN_SNAP_STEPS <= a.snap_per_unit) {
+					uint32_t* sp = a.snap + ((size_t)unit * a.snap_per_unit + (step / SCAN_SNAP_STEPS - 1)) * (SNAP_DW * 64) + lane;
+#pragma unroll
+					for (int r = 0; r < RP; r++) { sp[(2 * r) * 64] = (uint32_t)H[r]; sp[(2 * r + 1) * 64] = (uint32_t)E[r]; }
+					sp[(2 * RP) * 64] = (uint32_t)tc; sp[(2 * RP + 1) * 64] = (uint32_t)hbot; sp[(2 * RP + 2) * 64] = (uint32_t)fbot; sp[(2 * RP + 3) * 64] = (uint32_t)cm;
+					sp[(2 * RP + 4) * 64] = (uint32_t)recv_h_last; sp[(2 * RP + 5) * 64] = (uint32_t)fpo;
+				}
+			}
+			do_step(step); do_step(step + 1);
+		}
 		if (step < nsteps) do_step(step);
 		if (a.unit_hz && __builtin_amdgcn_ballot_w64(to_int(hzacc) != 0) != 0ull && lane == 0) atomicOr(a.unit_hz + unit, 1);
 		if (!DUMP && a.unit_first && first_enter != 0x7fffffff && lane == 0) atomicMin(a.unit_first + unit, first_enter);
@@ -471,10 +493,10 @@ static hipError_t launch_scan_dump_t(const ScanArgs& a, hipStream_t st)
 	hipError_t err = hipMemsetAsync(a.counter, 0, sizeof(uint32_t), st);
 	if (err != hipSuccess) return err;
 	const long blocks = ((long)a.nwork + 3) / 4;              // one unit per wave
-	// The LDS request is padded past half a CU's 160 KB so that a CU takes ONE workgroup and each of its four waves a SIMD of
-	// its own: left to itself the dispatcher packs these small workgroups onto a few CUs, and a wave that shares its SIMD's
-	// issue slot with three others takes three times as long -- this pass is on the critical path of its batch.
-	static const bool spread = [] { const char* e = getenv("FASIM_HAZARD_SPREAD"); return e ? atoi(e) != 0 : true; }();
+	// FASIM_HAZARD_SPREAD=1 pads the LDS request past half a CU's 160 KB, so that a CU takes ONE workgroup and each of its four
+	// waves a SIMD of its own (for measurements: it made no difference on an idle chip, and beside four workgroups of the main
+	// pass, 140 KB of LDS, such a request cannot start at all).
+	static const bool spread = [] { const char* e = getenv("FASIM_HAZARD_SPREAD"); return e ? atoi(e) != 0 : false; }();
 	const int lds = spread ? 84 * 1024 : 5 * SCAN_CODE_STRIDE;
 	static bool attr_set = false;                   // (benign race: the call is idempotent)
 	if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_scan<RP, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024); attr_set = true; }
@@ -509,6 +531,7 @@ static hipError_t launch_scan_t(const ScanArgs& a, hipStream_t st)
 // always full) with at most 24 rows per virtual lane
 int systolic_vs(int m) { const int seg = (m + 15) / 16; return 8 * ((seg + 191) / 192); }
 int systolic_tiles(int m) { return systolic_vs(m) / 8; }
+int systolic_snap_dwords(int m) { const int seg = (m + 15) / 16, vs = systolic_vs(m); return 2 * ((seg + vs - 1) / vs) + 6; }
 bool systolic_fits(int m) { const int seg = (m + 15) / 16; return seg >= 8 && systolic_tiles(m) <= 16; }
 
 hipError_t launch_scan(const ScanLaunch& L, hipStream_t st)
@@ -521,7 +544,7 @@ hipError_t launch_scan(const ScanLaunch& L, hipStream_t st)
 	for (int i = 0; i < 25; i++) a.score[i] = L.score[i];
 	a.colmax16 = L.colmax16; a.unit_hz = L.unit_hz; a.coarse = L.coarse;
 	a.vs = systolic_vs(L.m); a.ntiles = a.vs / 8; a.boundary = L.boundary;
-	a.unit_first = L.unit_first; a.dump_cols = L.dump_cols; a.dump_base = L.dump_base; a.dump_state = L.dump_state; a.rows_total = 16 * a.seg_len16;
+	a.unit_first = L.unit_first; a.snap = L.snap; a.snap_per_unit = L.snap_per_unit; a.dump_items = L.dump_items; a.dump_cols = L.dump_cols; a.dump_state = L.dump_state; a.rows_total = 16 * a.seg_len16;
 	if (a.ntiles > 1 && !a.boundary) return hipErrorInvalidValue;
 	// RP must be exactly ceil(segLen/vs): every virtual lane then owns RP or RP-1 rows.  One launch per tile of 128
 	// virtual lanes (long queries): tile t reads the bottom row tile t-1 left in `boundary` and overwrites it in place.
@@ -531,7 +554,7 @@ hipError_t launch_scan(const ScanLaunch& L, hipStream_t st)
 		a.tile = t;
 		hipError_t err = hipErrorInvalidValue;
 		switch (rp) {
-#define FASIM_SCAN_CASE(N) case N: err = L.dump_cols ? launch_scan_dump_t<N>(a, st) : (pair ? launch_scan_t<N, true>(a, st) : launch_scan_t<N, false>(a, st)); break;
+#define FASIM_SCAN_CASE(N) case N: err = L.dump_items ? launch_scan_dump_t<N>(a, st) : (pair ? launch_scan_t<N, true>(a, st) : launch_scan_t<N, false>(a, st)); break;
 		FASIM_SCAN_CASE(1) FASIM_SCAN_CASE(2) FASIM_SCAN_CASE(3) FASIM_SCAN_CASE(4) FASIM_SCAN_CASE(5) FASIM_SCAN_CASE(6)
 		FASIM_SCAN_CASE(7) FASIM_SCAN_CASE(8) FASIM_SCAN_CASE(9) FASIM_SCAN_CASE(10) FASIM_SCAN_CASE(11) FASIM_SCAN_CASE(12)
 		FASIM_SCAN_CASE(13) FASIM_SCAN_CASE(14) FASIM_SCAN_CASE(15) FASIM_SCAN_CASE(16) FASIM_SCAN_CASE(17) FASIM_SCAN_CASE(18)

@@ -59,9 +59,8 @@ const char* fasim_last_error(const fasim_engine* e);   /* e may be NULL: last gl
  * -1 restores the default of the last two.
  * key "host_threads": host threads for the host side of the batches, all workers of this engine together (default 3/8 of the
  * cores, at most 96, env FASIM_HOST_THREADS); several engines in one process should share the cores.
- * key "tail_split" / "tail_items": cooperative tail of a scan: the stage 3 of the last `tail_items` batches (default: one per
- * worker, -1) is cut into `tail_split` unit ranges (default 4, 0) that idle workers take over (env FASIM_TAIL_SPLIT,
- * FASIM_TAIL_ITEMS; tail_split 1 = every batch runs its stage 3 on its own worker). */
+ * key "tail_split" / "tail_items": cooperative tail of a scan: the stage 3 of the last `tail_items` batches (default 0: off)
+ * is cut into `tail_split` unit ranges (default 4) that idle workers take over (env FASIM_TAIL_SPLIT, FASIM_TAIL_ITEMS). */
 int fasim_set_option(fasim_engine* e, const char* key, int32_t value);
 
 /* Replaces ssw_init()/init_destroy() (ssw.h:78,83) and init_work() (stats.h:386): the lncRNA is

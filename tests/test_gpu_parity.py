@@ -759,6 +759,7 @@ def test_scan_queries_mixed_query_classes(mod, golden_dir, h19):
     p = mod.default_params(cLength=30)
     e = mod.Engine(0)
     e.set_option("seg_batch", 3)           # several items per query
+    e.set_option("tail_items", 4)          # cooperative tail on (off by default): the last items' stage 3 is shared among workers
     rnas = [q100, h19, malat, h19[:1600]]
     batch = e.scan_queries(rnas, dna, p)
     for q, rna in enumerate(rnas):
