@@ -92,6 +92,7 @@ struct fasim_engine {
 	int host_threads_total = 1;
 	int opt_workers = 0, opt_seg_batch = 0;      // fasim_set_option overrides (0 = default / environment)
 	int opt_taper = -1, opt_gate = -1;           // (-1 = default / environment)
+	int hz_chunks = -1, hz_snap = -1, hz_target = 0, hz_hot_w = 0;   // chunked hazard re-run: on/off, snapshots on/off (-1 = default / environment), chunk cost target, hot-column weight (0 = default)
 	int opt_tail_split = 0, opt_tail_items = -1; // cooperative tail: sub-tasks per batch (0 = default 4), batches at the end whose stage 3 is shared (-1 = default: none)
 	bool query_acgt = true;       // query holds only A,C,G,T: stage-1 and stage-2 scoring coincide on N-free segments
 	bool scan_v1 = false;         // FASIM_SCAN_V1=1: force the stripe-faithful kernels for stages 1 and 2
@@ -301,8 +302,9 @@ struct GateScope {
 
 // FASIM_HAZARD_CHUNKS=0: whole-unit re-run of the hazard units (the round-1 path); FASIM_HAZARD_SNAP=0: the checkpoint pass
 // runs every hazard unit from column 0 instead of from the main pass's pipeline snapshots (both for measurements)
-static bool hazard_chunks_enabled() { static const bool v = [] { const char* e = getenv("FASIM_HAZARD_CHUNKS"); return e ? atoi(e) != 0 : true; }(); return v; }
-static bool hazard_snapshots_enabled() { static const bool v = [] { const char* e = getenv("FASIM_HAZARD_SNAP"); return e ? atoi(e) != 0 : true; }(); return v; }
+// (options hazard_chunks / hazard_snapshots override the environment)
+static bool hazard_chunks_enabled(const fasim_engine* E) { static const bool v = [] { const char* e = getenv("FASIM_HAZARD_CHUNKS"); return e ? atoi(e) != 0 : true; }(); return E->hz_chunks >= 0 ? E->hz_chunks != 0 : v; }
+static bool hazard_snapshots_enabled(const fasim_engine* E) { static const bool v = [] { const char* e = getenv("FASIM_HAZARD_SNAP"); return e ? atoi(e) != 0 : true; }(); return E->hz_snap >= 0 ? E->hz_snap != 0 : v; }
 
 // Stripe-faithful re-run of the hazard units (Q2), cut into column chunks that run in PARALLEL (kernels.hip, "chunked hazard
 // re-run"; scan.hip, DUMP variant).
@@ -327,9 +329,11 @@ int run_hazard_chunked(fasim_engine* E, const UnitBatch& B, const std::vector<in
 	const int nh = (int)hz.size();
 	const int rows_total = 16 * ((E->m + 15) / 16);
 	const bool dbg = getenv("FASIM_DEBUG_HAZARD") != nullptr;
-	static const int target = [] { const char* e = getenv("FASIM_HAZARD_CHUNK_COLS"); const int v = e ? atoi(e) : 200; return v < 64 ? 64 : v; }();
+	static const int env_target = [] { const char* e = getenv("FASIM_HAZARD_CHUNK_COLS"); const int v = e ? atoi(e) : 200; return v < 64 ? 64 : v; }();
+	const int target = E->hz_target > 0 ? E->hz_target : env_target;
 	static const int hot_thr = [] { const char* e = getenv("FASIM_HAZARD_HOT_THR"); return e ? atoi(e) : 144; }();
-	static const int hot_w = [] { const char* e = getenv("FASIM_HAZARD_HOT_W"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 32 ? 32 : v); }();
+	static const int env_hot_w = [] { const char* e = getenv("FASIM_HAZARD_HOT_W"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 32 ? 32 : v); }();
+	const int hot_w = E->hz_hot_w > 0 ? E->hz_hot_w : env_hot_w;
 	static const bool spread = [] { const char* e = getenv("FASIM_HAZARD_SPREAD"); return e ? atoi(e) != 0 : false; }();      // (measured: no gain alone, and 84 KB of LDS cannot start beside four k_scan workgroups)
 	auto now = [] { return std::chrono::steady_clock::now(); };
 	auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
@@ -522,7 +526,7 @@ int run_scan_v2(fasim_engine* E, const UnitBatch& B, const std::vector<char>& un
 	L.unit_first = E->unit_first.as<int32_t>();
 	// pipeline snapshots for the chunked hazard re-run (single-tile queries): [unit][snapshot][dwords][64 lanes]
 	E->snap_units = 0; E->snap_per_unit = 0;
-	if (hazard_chunks_enabled() && systolic_fits(E->m) && systolic_tiles(E->m) == 1 && hazard_snapshots_enabled()) {
+	if (hazard_chunks_enabled(E) && systolic_fits(E->m) && systolic_tiles(E->m) == 1 && hazard_snapshots_enabled(E)) {
 		const int spu = (B.tstride + 127) / SCAN_SNAP_STEPS;
 		if (spu > 0) {
 			HIPOK(E->snap.ensure((size_t)nu * spu * systolic_snap_dwords(E->m) * 64 * sizeof(uint32_t)));
@@ -591,7 +595,7 @@ int run_scan_v2(fasim_engine* E, const UnitBatch& B, const std::vector<char>& un
 		if (st) st->hazard_units += (int64_t)hz.size();
 		HIPOK(E->colmax.ensure((size_t)nu * B.tstride));
 		HIPOK(E->max_out.ensure(sizeof(int32_t) * nu));
-		const bool chunked = hazard_chunks_enabled();
+		const bool chunked = hazard_chunks_enabled(E);
 		// (a query of more than one tile of 128 virtual lanes, > 3 072 nt, keeps the whole-unit re-run: the checkpoint pass does not
 		//  hand the restarted F chain from tile to tile)
 		if (chunked && systolic_tiles(E->m) == 1) { rc = run_hazard_chunked(E, B, hz, L); if (rc) return rc; }
@@ -1124,6 +1128,10 @@ int fasim_set_option(fasim_engine* E, const char* key, int32_t value)
 	else if (!strcmp(key, "seg_batch")) E->opt_seg_batch = value > 0 ? value : 0;
 	else if (!strcmp(key, "taper")) E->opt_taper = value;          // percent of the segments scanned in half-size batches at the end (-1: default)
 	else if (!strcmp(key, "heavy_gate")) E->opt_gate = value;      // k_scan / k_align_fwd launches in flight at once (0: no gate, -1: default)
+	else if (!strcmp(key, "hazard_chunks")) E->hz_chunks = value;          // 0: whole-unit stripe-faithful re-run; 1: column chunks (default)
+	else if (!strcmp(key, "hazard_snapshots")) E->hz_snap = value;        // 0: the checkpoint pass starts every unit at column 0
+	else if (!strcmp(key, "hazard_chunk_cols")) E->hz_target = value > 0 ? std::max(64, value) : 0;
+	else if (!strcmp(key, "hazard_hot_weight")) E->hz_hot_w = value > 0 ? std::min(32, value) : 0;
 	else if (!strcmp(key, "host_threads")) { if (value > 0) { E->host_threads = value; E->host_threads_total = value; } }   // host side of the batches (all workers together)
 	else if (!strcmp(key, "tail_split")) E->opt_tail_split = value > 0 ? value : 0;
 	else if (!strcmp(key, "tail_items")) E->opt_tail_items = value;
@@ -2023,6 +2031,7 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 		for (fasim_engine* w : ws) {
 			w->gate = (ws.size() > 1 && E->own_gate.cap > 0) ? &E->own_gate : nullptr;
 			w->scan_v1 = E->scan_v1; w->align_v1 = E->align_v1;
+			w->hz_chunks = E->hz_chunks; w->hz_snap = E->hz_snap; w->hz_target = E->hz_target; w->hz_hot_w = E->hz_hot_w;
 			w->host_threads = std::max(1, E->host_threads_total / nworkers);
 			HIPOK(hipSetDevice(E->device));
 			int rc = upload(w, w->enc_ids, encs.data(), sizeof(int) * nenc); if (rc) return rc;

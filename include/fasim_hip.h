@@ -59,6 +59,11 @@ const char* fasim_last_error(const fasim_engine* e);   /* e may be NULL: last gl
  * -1 restores the default of the last two.
  * key "host_threads": host threads for the host side of the batches, all workers of this engine together (default 3/8 of the
  * cores, at most 96, env FASIM_HOST_THREADS); several engines in one process should share the cores.
+ * key "hazard_chunks" (1) / "hazard_snapshots" (1) / "hazard_chunk_cols" (200) / "hazard_hot_weight" (2): the stripe-faithful
+ * re-run of the units the reference's signed lazy-F exit can touch: in parallel column chunks from checkpoints (0: one
+ * sequential run per unit), checkpoint pass continued from pipeline snapshots of the main scan (0: from column 0), cost target
+ * of a chunk in columns, price of a column whose maximum is >= 144 (env FASIM_HAZARD_CHUNKS, _SNAP, _CHUNK_COLS, _HOT_W).
+ * Results do not depend on any of them.
  * key "tail_split" / "tail_items": cooperative tail of a scan: the stage 3 of the last `tail_items` batches (default 0: off)
  * is cut into `tail_split` unit ranges (default 4) that idle workers take over (env FASIM_TAIL_SPLIT, FASIM_TAIL_ITEMS). */
 int fasim_set_option(fasim_engine* e, const char* key, int32_t value);

@@ -148,6 +148,29 @@ def test_q2_units_scan(mod, engine, h19, golden_dir, oracle_build):
     assert mod.tfosorted(res, chro, start, p) == open(os.path.join(golden_dir, "q2cat.TFOsorted"), "rb").read()
 
 
+@pytest.mark.parametrize("fixture", ["q2cat.fa", "planted40k.fa"])
+def test_hazard_rerun_variants_agree(mod, h19, golden_dir, fixture):
+    """The stripe-faithful re-run of the hazard units gives the same records however it is organised: one sequential run per
+    unit (round 1), column chunks from checkpoints of a pass that starts at column 0, the same from the pipeline snapshots
+    of the main scan (default), and with many small chunks (every chunk boundary is a place where a living Q2 deviation
+    has to be carried on by the group that came from the left)."""
+    _, dna = synth.read_fasta(os.path.join(golden_dir, fixture))
+    p = mod.default_params(cLength=20, overlapLength=0)
+    results = []
+    for opts in ({"hazard_chunks": 0}, {"hazard_chunks": 1, "hazard_snapshots": 0}, {"hazard_chunks": 1, "hazard_snapshots": 1},
+                 {"hazard_chunks": 1, "hazard_chunk_cols": 64, "hazard_hot_weight": 16}):
+        e = mod.Engine(0)
+        for k, v in opts.items():
+            e.set_option(k, v)
+        e.set_query(h19)
+        r = e.scan(dna, p)
+        results.append((r.recs, r.pool, r.stats["hazard_units"], r.stats["candidates"]))
+        e.close()
+    assert results[0][2] > 0                      # the fixtures do hold hazard units
+    for k in range(1, len(results)):
+        assert results[k] == results[0], k
+
+
 @pytest.mark.parametrize("name", ["meg3", "malat1", "neat1"])
 def test_long_queries_scan(mod, engine, golden_dir, name):
     """MEG3 (1 582 nt, 1 query tile), MALAT1 (8 708 nt, 3 tiles) and NEAT1 (22 767 nt, 8 tiles): the systolic kernels run
