@@ -529,8 +529,10 @@ int run_scan_v2(fasim_engine* E, const UnitBatch& B, const std::vector<char>& un
 	if (hazard_chunks_enabled(E) && systolic_fits(E->m) && systolic_tiles(E->m) == 1 && hazard_snapshots_enabled(E)) {
 		const int spu = (B.tstride + 127) / SCAN_SNAP_STEPS;
 		if (spu > 0) {
-			HIPOK(E->snap.ensure((size_t)nu * spu * systolic_snap_dwords(E->m) * 64 * sizeof(uint32_t)));
-			L.snap = E->snap.as<uint32_t>(); L.snap_per_unit = spu; E->snap_units = nu; E->snap_per_unit = spu;
+			// (an optimisation only: when the device has no room for it, the checkpoint pass starts at column 0)
+			if (E->snap.ensure((size_t)nu * spu * systolic_snap_dwords(E->m) * 64 * sizeof(uint32_t)) == hipSuccess) {
+				L.snap = E->snap.as<uint32_t>(); L.snap_per_unit = spu; E->snap_units = nu; E->snap_per_unit = spu;
+			} else (void)hipGetLastError();
 		}
 	}
 	if (E->st_heavy != E->st) HIPOK(hipStreamSynchronize(E->st));      // k_encode and the memset above ran on the other stream
