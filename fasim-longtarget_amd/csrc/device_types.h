@@ -71,7 +71,9 @@ struct AlignOutDev {           // 32-byte header; the CIGAR ops go to a compact 
 };
 
 // ---- row f3: forward sweep of classic SIM (sim.hip) ---------------------------------------------------
-struct SimEvent { uint32_t i, j; uint64_t key; };      // a cell above the threshold: row, column, (score + 2^20) << 26 | start_row << 13 | start_col
+struct SimEvent { uint32_t j, pad; uint64_t key; };     // a cell above the threshold: column (the row is implied by the buffer), (score + 2^20) << 26 | start_row << 13 | start_col
+struct SimNodeDev { int64_t score, stari, starj, endi, endj, top, bot, left, right; };   // = fasim_sim_node (fasim_hip.h)
+constexpr int SIM_K = 50;
 struct SimFwdArgs {
 	const uint8_t* tcodes;      // [unit][tstride] target letters as codes A0 C1 G2 T3 other 4
 	const int32_t* unit_len;
@@ -81,9 +83,10 @@ struct SimFwdArgs {
 	const int64_t* min_score;   // [unit] threshold of the first sweep (the reference compares the x10 scores with it, sim.h:567)
 	uint64_t* rowbuf;           // [unit][2][row_stride]: C and D of the last finished strip's bottom row
 	int64_t row_stride;
-	SimEvent* events;           // [unit][event_cap]
-	uint32_t event_cap;
-	uint32_t* event_count;      // [unit], zeroed by the caller; may exceed event_cap (then the caller retries with more room)
+	SimEvent* events;           // [unit][64 rows of the strip in flight][event_cap]: the cells above the threshold, row by row
+	uint32_t event_cap;         // >= the longest unit: a row cannot overflow
+	SimNodeDev* nodes;          // [unit][SIM_K]: the node list after the sweep
+	int32_t* node_count;        // [unit]
 };
 
 // packed 4-bit score table: entry q (0..5) of row t = score(t,q)+BIAS

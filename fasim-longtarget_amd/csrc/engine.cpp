@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <sched.h>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -79,7 +80,7 @@ struct fasim_engine {
 		stage1, hits, hits_total, hit_off, hit_cnt, thr, ends, bprobs, bout, scratch, colmax16, unit_ids, flags, stage1_in, hits2,
 		fprobs, ftasks, fstream, fout, aout, cigpool, cigcount, forder, scratch2, boundary, fboundary, unit_hz,
 		unit_first, hz_cols, hz_plan, hz_base, hz_items, snap, hz_state, hz_rows, hz_chunk, hz_src, hz_zero,   // chunked hazard re-run
-		qsim, sim_min, sim_row, sim_ev, sim_cnt;      // -F: query codes of the SIM alphabet, thresholds, strip row buffer, events, counters
+		qsim, sim_min, sim_row, sim_ev, sim_cnt, sim_nodes;      // -F: query codes of the SIM alphabet, thresholds, strip row buffer, events, counters
 	bool align_v1 = false;        // FASIM_ALIGN_V1=1: force the stripe-faithful kernels for stage 3
 	std::vector<fasim_engine*> workers;   // extra engines on the same device: batches in flight concurrently
 	// Gate for the two GPU-filling kernels (k_scan, k_align_fwd).  Without it the workers fall into lock step: all of them
@@ -90,6 +91,8 @@ struct fasim_engine {
 	HeavyGate own_gate;
 	HeavyGate* gate = nullptr;            // shared by the workers of one fasim_scan (points at the parent's own_gate)
 	int host_threads_total = 1;
+	bool host_threads_explicit = false;          // FASIM_HOST_THREADS / option host_threads given: -F keeps to it too
+	int sim_threads = 1;                         // -F: host threads of this worker for the finish half (all cores shared by the batches in flight)
 	int opt_workers = 0, opt_seg_batch = 0;      // fasim_set_option overrides (0 = default / environment)
 	int opt_taper = -1, opt_gate = -1;           // (-1 = default / environment)
 	int hz_chunks = -1, hz_snap = -1, hz_target = 0, hz_hot_w = 0;   // chunked hazard re-run: on/off, snapshots on/off (-1 = default / environment), chunk cost target, hot-column weight (0 = default)
@@ -299,6 +302,21 @@ struct GateScope {
 	}
 	~GateScope() { release(); }
 };
+
+// cores this process may really use: scheduler affinity, capped by the cgroup CPU quota when there is one
+// (std::thread::hardware_concurrency() reports the whole host on a shared GPU node)
+static int usable_cores()
+{
+	int n = (int)std::max(1u, std::thread::hardware_concurrency());
+	cpu_set_t set;
+	if (sched_getaffinity(0, sizeof set, &set) == 0) { const int a = CPU_COUNT(&set); if (a > 0) n = std::min(n, a); }
+	if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+		char q[64] = { 0 }; long long period = 0;
+		if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) { const long long c = atoll(q) / period; if (c >= 1) n = (int)std::min<long long>(n, c); }
+		fclose(f);
+	}
+	return std::max(1, n);
+}
 
 // FASIM_HAZARD_CHUNKS=0: whole-unit re-run of the hazard units (the round-1 path); FASIM_HAZARD_SNAP=0: the checkpoint pass
 // runs every hazard unit from column 0 instead of from the main pass's pipeline snapshots (both for measurements)
@@ -1094,6 +1112,7 @@ int fasim_engine_create(int device, fasim_engine** out)
 	// the batches in flight; 3/8 of the cores (96 on the 256-thread GPU hosts) keeps the burst of a batch below ~50 ms
 	E->host_threads = env ? std::max(1, atoi(env)) : (int)std::min(96u, std::max(1u, hc * 3 / 8));
 	E->host_threads_total = E->host_threads;
+	E->host_threads_explicit = env != nullptr;
 	const char* v1 = getenv("FASIM_SCAN_V1");
 	E->scan_v1 = v1 && atoi(v1) != 0;
 	const char* a1 = getenv("FASIM_ALIGN_V1");
@@ -1113,7 +1132,7 @@ void fasim_engine_destroy(fasim_engine* e)
 		&e->ends, &e->bprobs, &e->bout, &e->scratch, &e->dna_res, &e->colmax16, &e->unit_ids, &e->flags, &e->stage1_in, &e->hits2,
 		&e->fprobs, &e->ftasks, &e->fstream, &e->fout, &e->aout, &e->cigpool, &e->cigcount, &e->forder, &e->scratch2, &e->boundary, &e->fboundary, &e->unit_hz,
 		&e->unit_first, &e->hz_cols, &e->hz_plan, &e->hz_base, &e->hz_items, &e->snap, &e->hz_state, &e->hz_rows, &e->hz_chunk, &e->hz_src, &e->hz_zero,
-		&e->qsim, &e->sim_min, &e->sim_row, &e->sim_ev, &e->sim_cnt };
+		&e->qsim, &e->sim_min, &e->sim_row, &e->sim_ev, &e->sim_cnt, &e->sim_nodes };
 	for (auto& t : e->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
 	for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
 	for (DevBuf* b : bufs) b->release();
@@ -1134,7 +1153,7 @@ int fasim_set_option(fasim_engine* E, const char* key, int32_t value)
 	else if (!strcmp(key, "hazard_snapshots")) E->hz_snap = value;        // 0: the checkpoint pass starts every unit at column 0
 	else if (!strcmp(key, "hazard_chunk_cols")) E->hz_target = value > 0 ? std::max(64, value) : 0;
 	else if (!strcmp(key, "hazard_hot_weight")) E->hz_hot_w = value > 0 ? std::min(32, value) : 0;
-	else if (!strcmp(key, "host_threads")) { if (value > 0) { E->host_threads = value; E->host_threads_total = value; } }   // host side of the batches (all workers together)
+	else if (!strcmp(key, "host_threads")) { if (value > 0) { E->host_threads = value; E->host_threads_total = value; E->host_threads_explicit = true; } }   // host side of the batches (all workers together)
 	else if (!strcmp(key, "tail_split")) E->opt_tail_split = value > 0 ? value : 0;
 	else if (!strcmp(key, "tail_items")) E->opt_tail_items = value;
 	else return fail(E, FASIM_E_ARG, "unknown option %s", key);
@@ -1234,108 +1253,49 @@ int fasim_ssw_colmax_word(fasim_engine* E, const char* target, int32_t n, int32_
 // addnode() (sim.h:99-148) over the events of one unit in row-major order: a known start point is updated (strictly larger
 // score moves the end point; the bounding box grows), a new one is appended or, with K nodes present, overwrites the first
 // node of lowest score whatever its own score is.
-static void sim_replay_nodes(const std::vector<SimEvent>& ev, std::vector<fasim_sim_node>& nodes)
-{
-	nodes.clear();
-	for (const SimEvent& e : ev) {
-		const int64_t c = (int64_t)(e.key >> 26) - ((int64_t)1 << 20);
-		const int64_t ci = (int64_t)((e.key >> 13) & 0x1fff), cj = (int64_t)(e.key & 0x1fff), i = e.i, j = e.j;
-		bool found = false;
-		for (fasim_sim_node& n : nodes) {
-			if (n.stari != ci || n.starj != cj) continue;
-			if (n.score < c) { n.score = c; n.endi = i; n.endj = j; }
-			if (n.top > i) n.top = i;
-			if (n.bot < i) n.bot = i;
-			if (n.left > j) n.left = j;
-			if (n.right < j) n.right = j;
-			found = true;
-			break;
-		}
-		if (found) continue;
-		const fasim_sim_node fresh = { c, ci, cj, i, j, i, i, j, j };
-		if ((int)nodes.size() == FASIM_SIM_K) {
-			size_t low = 0;
-			for (size_t d = 1; d < nodes.size(); d++) if (nodes[d].score < nodes[low].score) low = d;
-			nodes[low] = fresh;
-		} else nodes.push_back(fresh);
-	}
-}
-
-// Forward sweep + node-list replay for units [first, first + nrun) of a resident code buffer.  min_scores[u] belongs to unit
-// first + u.  lists[u] receives the node list.  Units are processed in slices whose event buffers fit ~2 GiB; a unit whose
-// events overflow the first guess (one cell in six) is run again with room for every cell.  The replay (order dependent,
-// ~10^6 events per 5 kb unit) runs on `threads` host threads, one unit each.
+// Forward sweep + node list (k_sim_forward: the list is kept and replayed inside the wave, sim.hip) for units
+// [first, first + nrun) of a resident code buffer.  min_scores[u] belongs to unit first + u.  lists[u] receives the node list.
+// Units run in slices of <= 1024 (64 row segments of one unit's length each = 5 MB of scratch per unit); *ready (if given) is
+// the number of leading units whose lists are complete, so that the host half can start on a slice while the next one runs.
+// `lists` must have been sized to nrun by the caller.
 static int sim_forward_units(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, const int32_t* unit_len_dev, const int32_t* unit_len_host,
-	int first, int nrun, const int64_t* min_scores, int threads, std::vector<std::vector<fasim_sim_node>>& lists)
+	int first, int nrun, const int64_t* min_scores, std::atomic<int>* ready, std::vector<std::vector<fasim_sim_node>>& lists)
 {
-	lists.assign((size_t)nrun, std::vector<fasim_sim_node>());
+	static_assert(sizeof(SimNodeDev) == sizeof(fasim_sim_node) && SIM_K == FASIM_SIM_K, "node layout");
 	if (nrun <= 0) return FASIM_OK;
 	int maxlen = 1;
 	for (int u = 0; u < nrun; u++) maxlen = std::max(maxlen, unit_len_host[first + u]);
 	if (E->m > 8191 || maxlen > 8191) return fail(E, FASIM_E_UNSUPPORTED, "the SIM forward sweep holds start points in 13 bits: query %d / target %d nt is too long", E->m, maxlen);
 	const int64_t row_stride = (maxlen + 2 + 15) & ~15;
-	DevBuf& d_min = E->sim_min; DevBuf& d_row = E->sim_row; DevBuf& d_ev = E->sim_ev; DevBuf& d_cnt = E->sim_cnt;
+	const uint32_t cap = (uint32_t)((maxlen + 15) & ~15);
+	DevBuf& d_min = E->sim_min; DevBuf& d_row = E->sim_row; DevBuf& d_ev = E->sim_ev; DevBuf& d_cnt = E->sim_cnt; DevBuf& d_nodes = E->sim_nodes;
 	int rc = upload(E, d_min, min_scores, sizeof(int64_t) * nrun); if (rc) return rc;
-	std::vector<int> todo((size_t)nrun);
-	for (int u = 0; u < nrun; u++) todo[(size_t)u] = u;
-	size_t cap = std::max<size_t>(4096, (size_t)E->m * (size_t)maxlen / 6);
-	for (int attempt = 0; attempt < 2 && !todo.empty(); attempt++, cap = (size_t)E->m * (size_t)maxlen + 64) {
-		const size_t per_slice = std::max<size_t>(1, std::min<size_t>(256, ((size_t)2 << 30) / (cap * sizeof(SimEvent))));
-		std::vector<int> next;
-		size_t r0 = 0;
-		while (r0 < todo.size()) {
-			// a launch covers a contiguous run of units (the kernel indexes everything by blockIdx)
-			size_t r1 = r0 + 1;
-			while (r1 < todo.size() && r1 - r0 < per_slice && todo[r1] == todo[r1 - 1] + 1) r1++;
-			const int u0 = todo[r0], cnt = (int)(r1 - r0);
-			HIPOK(d_ev.ensure((size_t)cnt * cap * sizeof(SimEvent)));
-			HIPOK(d_row.ensure((size_t)cnt * 2 * row_stride * sizeof(uint64_t)));
-			HIPOK(d_cnt.ensure(sizeof(uint32_t) * cnt));
-			HIPOK(hipMemsetAsync(d_cnt.p, 0, sizeof(uint32_t) * cnt, E->st));
-			SimFwdArgs a;
-			a.tcodes = tcodes_dev + (size_t)(first + u0) * tstride; a.unit_len = unit_len_dev + first + u0; a.tstride = tstride;
-			a.qcodes = E->qsim.as<uint8_t>(); a.m = E->m; a.min_score = d_min.as<int64_t>() + u0;
-			a.rowbuf = d_row.as<uint64_t>(); a.row_stride = row_stride;
-			a.events = d_ev.as<SimEvent>(); a.event_cap = (uint32_t)cap; a.event_count = d_cnt.as<uint32_t>();
-			hipError_t he;
-			{ TimedScope ts(E, 7); he = launch_sim_forward(a, cnt, E->st); }
-			if (he != hipSuccess) return fail(E, FASIM_E_HIP, "sim_forward launch failed: %s", hipGetErrorString(he));
-			std::vector<uint32_t> cnts((size_t)cnt);
-			HIPOK(hipMemcpyAsync(cnts.data(), d_cnt.p, sizeof(uint32_t) * cnt, hipMemcpyDeviceToHost, E->st));
-			HIPOK(hipStreamSynchronize(E->st));
-			std::vector<std::vector<SimEvent>> evs((size_t)cnt);
-			for (int k = 0; k < cnt; k++) {
-				if (cnts[(size_t)k] > cap) { next.push_back(u0 + k); continue; }
-				evs[(size_t)k].resize(cnts[(size_t)k]);
-				if (cnts[(size_t)k]) HIPOK(hipMemcpyAsync(evs[(size_t)k].data(), d_ev.as<SimEvent>() + (size_t)k * cap, sizeof(SimEvent) * cnts[(size_t)k], hipMemcpyDeviceToHost, E->st));
-			}
-			HIPOK(hipStreamSynchronize(E->st));
-			std::atomic<int> nextk(0);
-			auto work = [&]() {
-				std::vector<SimEvent> sorted; std::vector<uint32_t> start;
-				for (;;) {
-					const int k = nextk.fetch_add(1);
-					if (k >= cnt) break;
-					if (cnts[(size_t)k] > cap) continue;
-					const std::vector<SimEvent>& ev = evs[(size_t)k];
-					// events arrive in (step, lane) order: within one row the columns ascend; a stable bucket pass by row gives
-					// the row-major order addnode needs
-					start.assign((size_t)E->m + 2, 0);
-					for (const SimEvent& e : ev) start[(size_t)e.i + 1]++;
-					for (size_t r = 1; r < start.size(); r++) start[r] += start[r - 1];
-					sorted.resize(ev.size());
-					for (const SimEvent& e : ev) sorted[start[(size_t)e.i]++] = e;
-					sim_replay_nodes(sorted, lists[(size_t)(u0 + k)]);
-				}
-			};
-			const int nt = std::max(1, std::min(threads, cnt));
-			if (nt == 1) work();
-			else { std::vector<std::thread> th; for (int t = 0; t < nt; t++) th.emplace_back(work); for (auto& t : th) t.join(); }
-			r0 = r1;
+	const int per_slice = 1024;         // waves in flight: the sweep of one unit takes ~1.5 s of one wave, the chip holds thousands
+	std::vector<fasim_sim_node> hn((size_t)per_slice * FASIM_SIM_K);
+	std::vector<int32_t> hc((size_t)per_slice);
+	for (int u0 = 0; u0 < nrun; u0 += per_slice) {
+		const int cnt = std::min(per_slice, nrun - u0);
+		HIPOK(d_ev.ensure((size_t)cnt * 64 * cap * sizeof(SimEvent)));
+		HIPOK(d_row.ensure((size_t)cnt * 2 * row_stride * sizeof(uint64_t)));
+		HIPOK(d_cnt.ensure(sizeof(int32_t) * cnt));
+		HIPOK(d_nodes.ensure(sizeof(SimNodeDev) * (size_t)cnt * SIM_K));
+		SimFwdArgs a;
+		a.tcodes = tcodes_dev + (size_t)(first + u0) * tstride; a.unit_len = unit_len_dev + first + u0; a.tstride = tstride;
+		a.qcodes = E->qsim.as<uint8_t>(); a.m = E->m; a.min_score = d_min.as<int64_t>() + u0;
+		a.rowbuf = d_row.as<uint64_t>(); a.row_stride = row_stride;
+		a.events = d_ev.as<SimEvent>(); a.event_cap = cap; a.nodes = d_nodes.as<SimNodeDev>(); a.node_count = d_cnt.as<int32_t>();
+		hipError_t he;
+		{ TimedScope ts(E, 7); he = launch_sim_forward(a, cnt, E->st); }
+		if (he != hipSuccess) return fail(E, FASIM_E_HIP, "sim_forward launch failed: %s", hipGetErrorString(he));
+		HIPOK(hipMemcpyAsync(hc.data(), d_cnt.p, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, E->st));
+		HIPOK(hipMemcpyAsync(hn.data(), d_nodes.p, sizeof(fasim_sim_node) * (size_t)cnt * FASIM_SIM_K, hipMemcpyDeviceToHost, E->st));
+		HIPOK(hipStreamSynchronize(E->st));
+		for (int k = 0; k < cnt; k++) {
+			if (hc[(size_t)k] < 0 || hc[(size_t)k] > FASIM_SIM_K) return fail(E, FASIM_E_HIP, "sim_forward: bad node count");
+			lists[(size_t)(u0 + k)].assign(hn.begin() + (size_t)k * FASIM_SIM_K, hn.begin() + (size_t)k * FASIM_SIM_K + hc[(size_t)k]);
 		}
-		todo.swap(next);
+		if (ready) ready->store(u0 + cnt, std::memory_order_release);
 	}
-	if (!todo.empty()) return fail(E, FASIM_E_HIP, "sim_forward: event buffer overflow after the retry");
 	return FASIM_OK;
 }
 
@@ -1370,8 +1330,8 @@ int fasim_sim_forward_batch(fasim_engine* E, const char* targets, const int64_t*
 	for (int k = 0; k < nprob; k++) for (int c = 0; c < lens[k]; c++) tc[(size_t)k * tstride + c] = sim_code(targets[offsets[k] + c]);
 	rc = upload(E, E->tcodes, tc.data(), tc.size()); if (rc) return rc;
 	rc = upload(E, E->unit_len, lens, sizeof(int32_t) * nprob); if (rc) return rc;
-	std::vector<std::vector<fasim_sim_node>> lists;
-	rc = sim_forward_units(E, E->tcodes.as<uint8_t>(), tstride, E->unit_len.as<int32_t>(), lens, 0, nprob, min_scores, E->host_threads, lists);
+	std::vector<std::vector<fasim_sim_node>> lists((size_t)nprob);
+	rc = sim_forward_units(E, E->tcodes.as<uint8_t>(), tstride, E->unit_len.as<int32_t>(), lens, 0, nprob, min_scores, nullptr, lists);
 	if (rc) return rc;
 	for (int k = 0; k < nprob; k++) {
 		counts[k] = (int32_t)lists[(size_t)k].size();
@@ -1618,27 +1578,32 @@ int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t*
 			t0 = now_s();
 			std::vector<int64_t> mins((size_t)B.nunit);
 			for (int u = 0; u < B.nunit; u++) mins[(size_t)u] = thr[(size_t)u];
-			std::vector<std::vector<fasim_sim_node>> lists;
-			rc = sim_forward_units(E, E->tcodes.as<uint8_t>(), tstride, E->unit_len.as<int32_t>(), B.unit_len.data(), 0, B.nunit, mins.data(),
-				E->host_threads, lists);
-			if (rc) return rc;
+			std::vector<std::vector<fasim_sim_node>> lists((size_t)B.nunit);
 			std::vector<std::vector<HostTriplex>>& per_unit = C.per_unit;
 			per_unit.assign((size_t)B.nunit, std::vector<HostTriplex>());
-			std::atomic<int> next(0);
+			// the host threads finish the units of a slice while the GPU sweeps the next one
+			std::atomic<int> next(0), ready(0);
+			std::atomic<bool> abort(false);
 			auto work = [&]() {
 				std::string target, src;
 				for (;;) {
 					const int u = next.fetch_add(1);
 					if (u >= B.nunit) break;
+					while (u >= ready.load(std::memory_order_acquire) && !abort.load()) std::this_thread::sleep_for(std::chrono::microseconds(200));
+					if (abort.load()) break;
 					const int s = u / nenc, enc = encs[(size_t)(u % nenc)];
 					encode_unit_host(dna + sidx[(size_t)s] * step, slen[(size_t)s], enc, target, src);
 					sim_finish_unit(E->rna, target, src, (long)(sidx[(size_t)s] * step), thr[(size_t)u], enc, p, lists[(size_t)u], per_unit[(size_t)u]);
 					for (HostTriplex& t : per_unit[(size_t)u]) { t.seg = (int)sidx[(size_t)s]; t.enc = enc; }
 				}
 			};
-			const int nt = std::max(1, std::min(E->host_threads, B.nunit));
-			if (nt == 1) work();
-			else { std::vector<std::thread> th; for (int k = 0; k < nt; k++) th.emplace_back(work); for (auto& t : th) t.join(); }
+			const int nt = std::max(1, std::min(E->sim_threads, B.nunit));
+			std::vector<std::thread> th;
+			for (int k = 0; k < nt; k++) th.emplace_back(work);
+			rc = sim_forward_units(E, E->tcodes.as<uint8_t>(), tstride, E->unit_len.as<int32_t>(), B.unit_len.data(), 0, B.nunit, mins.data(), &ready, lists);
+			if (rc) abort.store(true);
+			for (auto& t : th) t.join();
+			if (rc) return rc;
 			st.t_stage3_s += now_s() - t0;
 			C.stage3_done = true;
 			return FASIM_OK;
@@ -2035,6 +2000,11 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 			w->scan_v1 = E->scan_v1; w->align_v1 = E->align_v1;
 			w->hz_chunks = E->hz_chunks; w->hz_snap = E->hz_snap; w->hz_target = E->hz_target; w->hz_hot_w = E->hz_hot_w;
 			w->host_threads = std::max(1, E->host_threads_total / nworkers);
+			{
+				// -F: the finish half of classic SIM is ~40 ms of host work per unit and nothing else needs the cores meanwhile
+				const int all = E->host_threads_explicit ? E->host_threads_total : usable_cores();
+				w->sim_threads = std::max(1, all / (int)std::max<size_t>(1, std::min<size_t>((size_t)nworkers, items.size())));
+			}
 			HIPOK(hipSetDevice(E->device));
 			int rc = upload(w, w->enc_ids, encs.data(), sizeof(int) * nenc); if (rc) return rc;
 			drain_timed(w);

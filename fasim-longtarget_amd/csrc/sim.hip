@@ -3,18 +3,23 @@
 // What it replaces: the first double loop of SIM() (sim.h:506-571): affine-gap local alignment scores of the whole
 // (lncRNA x target) matrix where every cell also carries the START POINT of its best alignment, with the reference's
 // tie-break ORDER (sim.h:481-493): larger score, then larger start row, then larger start column.  Cells whose score
-// exceeds the threshold go to the K = 50 node list (addnode, sim.h:99-148), which is order dependent; the kernel
-// therefore only EMITS those cells and the host replays the list (engine.cpp, sim_replay_nodes).
+// exceeds the threshold go to the K = 50 node list (addnode, sim.h:99-148), which is order dependent (row-major).
 //
 // Layout: one wave64 per unit.  The query rows are cut into strips of 64 (lane = row); a strip is swept over the target
 // columns as a wavefront (lane l works on column step - l), so the left neighbour is the lane's own previous cell and the
 // upper / diagonal neighbours arrive from lane l-1 by a wave shift.  Lane 63 leaves the strip's bottom row (C and D per
 // column) in a per-unit row buffer in HBM, which lane 0 of the next strip reads back 64 columns at a time.
 //
+// The node list lives in the wave too: lane k holds node k (score, start, end, bounding box).  A lane appends the cells of
+// ITS row that pass the threshold to the row's own segment of a per-unit scratch buffer (columns ascend with the steps), and
+// after each strip the wave replays the 64 segments in row order through addnode: the search for a node with the same start
+// point is one compare + ballot, the eviction of the first lowest-score node a wave minimum over (score, lane).  That is
+// the row-major order of the reference without a sort, and nothing but the 50 nodes ever leaves the GPU.
+//
 // A DP state = one 64-bit key  (score + SIM_BIAS) << 26 | start_row << 13 | start_col,  so ORDER is an unsigned 64-bit max
 // and "score - k" is a subtraction in the top field.  Scores are the reference's x10 values (match 50, mismatch -40, gap
-// open 120, extension 40).  Limits of this first version: query and target at most 8191 long (13-bit start fields).
-// Integer DP: no MFMA.  Plain 64-bit VALU arithmetic, not yet tuned (this is the first kernel of the row).
+// open 120, extension 40).  Limits: query and target at most 8191 long (13-bit start fields).
+// Integer DP: no MFMA.  Plain 64-bit VALU arithmetic, not yet tuned.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernels.h"
@@ -48,8 +53,11 @@ __global__ void __launch_bounds__(64) k_sim_forward(SimFwdArgs a)
 	const uint8_t* tc_unit = a.tcodes + (int64_t)unit * a.tstride;
 	uint64_t* rowC = a.rowbuf + (int64_t)unit * 2 * a.row_stride;      // [0 .. N]: C of the finished strip's bottom row
 	uint64_t* rowD = rowC + a.row_stride;
-	SimEvent* ev = a.events + (int64_t)unit * a.event_cap;
-	uint32_t* count = a.event_count + unit;
+	SimEvent* seg = a.events + ((int64_t)unit * 64 + lane) * a.event_cap;      // my row's segment
+	// node list: lane k < nn holds node k
+	int nn = 0;
+	int n_score = 0, n_stari = 0, n_starj = 0, n_endi = 0, n_endj = 0, n_top = 0, n_bot = 0, n_left = 0, n_right = 0;
+	const int64_t thr = a.min_score[unit];
 	const uint64_t Rk = (uint64_t)SIM_R << SIM_SHIFT, QRk = (uint64_t)(SIM_Q + SIM_R) << SIM_SHIFT;
 	const int nstrips = (M + 63) / 64;
 
@@ -64,6 +72,7 @@ __global__ void __launch_bounds__(64) k_sim_forward(SimFwdArgs a)
 		uint64_t diag = sim_key(0, (uint32_t)(i - 1), 0);    // P for column 1: p = 0, (pi, pj) = (i - 1, 0)
 		uint64_t bufC = 0, bufD = 0;                         // row-buffer chunk (lane l holds column chunk0 + l + 1)
 		int tchunk = 0, tcode = 0;
+		int nev = 0;                                         // cells of my row above the threshold in this strip
 		const int nsteps = N + last_lane + 1;
 		for (int step = 0; step < nsteps; step++) {
 			if ((step & 63) == 0) {
@@ -96,16 +105,44 @@ __global__ void __launch_bounds__(64) k_sim_forward(SimFwdArgs a)
 			}
 			if (j >= 1) diag = upC;                                                                    // C[i-1][j] is the diagonal of column j + 1
 			                                                                                           // (before column 1 the start value (i-1, 0) stays)
-			// cells above the threshold: compacted per step, in (step, lane) order
-			const bool hit = valid && sim_score(c) > a.min_score[unit];
-			const unsigned long long b = __ballot(hit);
-			if (b) {
-				uint32_t base = 0;
-				if (lane == 0) base = atomicAdd(count, (uint32_t)__popcll(b));
-				base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-				if (hit) {
-					const uint32_t slot = base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
-					if (slot < a.event_cap) { SimEvent e; e.i = (uint32_t)i; e.j = (uint32_t)j; e.key = c; ev[slot] = e; }
+			// cells above the threshold: appended to my row's segment (columns ascend)
+			if (valid && sim_score(c) > thr) { SimEvent e; e.j = (uint32_t)j; e.pad = 0; e.key = c; seg[nev] = e; nev++; }
+		}
+		// ---- replay of the strip's rows through addnode (sim.h:99-148), in row order; 64 events per load
+		// (the segments are rewritten strip after strip and read by other lanes of the wave: device-scope fence, so that no
+		//  load is served from a line cached before the store)
+		__builtin_amdgcn_s_waitcnt(0);
+		__threadfence();
+		for (int r = 0; r <= last_lane; r++) {
+			const int cnt = __builtin_amdgcn_readlane(nev, r);
+			const SimEvent* rs = a.events + ((int64_t)unit * 64 + r) * a.event_cap;
+			const int ei = strip * 64 + r + 1;                         // the row of these cells
+			for (int e0 = 0; e0 < cnt; e0 += 64) {
+				const int nb = min(64, cnt - e0);
+				uint32_t ej = 0, klo = 0, khi = 0;
+				if (lane < nb) { const SimEvent e = rs[e0 + lane]; ej = e.j; klo = (uint32_t)e.key; khi = (uint32_t)(e.key >> 32); }
+				for (int x = 0; x < nb; x++) {
+					const int j = __builtin_amdgcn_readlane((int)ej, x);
+					const uint64_t key = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)khi, x) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)klo, x);
+					const int c = (int)sim_score(key), ci = (int)((key >> 13) & 0x1fff), cj = (int)(key & 0x1fff);
+					const unsigned long long hit = __ballot(lane < nn && n_stari == ci && n_starj == cj);
+					int target;
+					bool fresh;
+					if (hit) { target = (int)__builtin_ctzll(hit); fresh = false; }
+					else if (nn < SIM_K) { target = nn; nn++; fresh = true; }
+					else {
+						// the first node of lowest score gives way (sim.h:129-136)
+						long long v = lane < SIM_K ? (((long long)n_score << 6) | lane) : 0x7fffffffffffffffll;
+						for (int o = 32; o; o >>= 1) { const long long w = __shfl_xor(v, o, 64); v = w < v ? w : v; }
+						target = (int)(v & 63); fresh = true;
+					}
+					if (lane == target) {
+						if (fresh) { n_score = c; n_stari = ci; n_starj = cj; n_endi = ei; n_endj = j; n_top = n_bot = ei; n_left = n_right = j; }
+						else {
+							if (n_score < c) { n_score = c; n_endi = ei; n_endj = j; }
+							n_top = min(n_top, ei); n_bot = max(n_bot, ei); n_left = min(n_left, j); n_right = max(n_right, j);
+						}
+					}
 				}
 			}
 		}
@@ -114,6 +151,12 @@ __global__ void __launch_bounds__(64) k_sim_forward(SimFwdArgs a)
 		__builtin_amdgcn_s_waitcnt(0);
 		__threadfence_block();
 	}
+	if (lane < nn) {
+		SimNodeDev o;
+		o.score = n_score; o.stari = n_stari; o.starj = n_starj; o.endi = n_endi; o.endj = n_endj; o.top = n_top; o.bot = n_bot; o.left = n_left; o.right = n_right;
+		a.nodes[(int64_t)unit * SIM_K + lane] = o;
+	}
+	if (lane == 0) a.node_count[unit] = nn;
 }
 
 hipError_t launch_sim_forward(const SimFwdArgs& a, int32_t nunit, hipStream_t st)
