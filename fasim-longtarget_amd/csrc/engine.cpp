@@ -1099,6 +1099,13 @@ int fasim_engine_create(int device, fasim_engine** out)
 			for (int cu = 0; cu < 256; cu++) { const bool l = (cu % every) == every - 1 && (cu / every) < nl; (l ? light : heavy)[cu >> 5] |= 1u << (cu & 31); }
 			he = hipExtStreamCreateWithCUMask(&E->st, 8, light);
 			if (he == hipSuccess) he = hipExtStreamCreateWithCUMask(&E->st_heavy, 8, heavy);
+		} else if (he == hipSuccess && getenv("FASIM_STREAM_PRIO") && atoi(getenv("FASIM_STREAM_PRIO")) > 0) {
+			// FASIM_STREAM_PRIO=1: the latency-bound kernels of a batch on a high-priority stream, k_scan / k_align_fwd on a
+			// low-priority one (measured: see DESIGN.md section 4)
+			int least = 0, greatest = 0;
+			he = hipDeviceGetStreamPriorityRange(&least, &greatest);
+			if (he == hipSuccess) he = hipStreamCreateWithPriority(&E->st, hipStreamDefault, greatest);
+			if (he == hipSuccess) he = hipStreamCreateWithPriority(&E->st_heavy, hipStreamDefault, least);
 		} else if (he == hipSuccess) { he = hipStreamCreate(&E->st); E->st_heavy = E->st; }
 	}
 	if (he != hipSuccess) { int rc = fail(nullptr, FASIM_E_NODEVICE, "cannot initialise device %d: %s", device, hipGetErrorString(he)); delete E; return rc; }
