@@ -92,6 +92,7 @@ struct fasim_engine {
 	HeavyGate* gate = nullptr;            // shared by the workers of one fasim_scan (points at the parent's own_gate)
 	int host_threads_total = 1;
 	bool host_threads_explicit = false;          // FASIM_HOST_THREADS / option host_threads given: -F keeps to it too
+	std::thread reaper;                          // frees the host lists of the previous scan in the background
 	int sim_threads = 1;                         // -F: host threads of this worker for the finish half (all cores shared by the batches in flight)
 	int opt_workers = 0, opt_seg_batch = 0;      // fasim_set_option overrides (0 = default / environment)
 	int opt_taper = -1, opt_gate = -1;           // (-1 = default / environment)
@@ -1131,6 +1132,7 @@ int fasim_engine_create(int device, fasim_engine** out)
 void fasim_engine_destroy(fasim_engine* e)
 {
 	if (!e) return;
+	if (e->reaper.joinable()) e->reaper.join();
 	for (fasim_engine* w : e->workers) fasim_engine_destroy(w);
 	e->workers.clear();
 	(void)hipSetDevice(e->device);
@@ -1892,6 +1894,53 @@ static int pack_result(fasim_engine* E, std::vector<HostTriplex>& all, const fas
 	return FASIM_OK;
 }
 
+// The same from the batches' lists as they are (one query's batches in canonical order): record and pool positions of every
+// batch follow from a prefix sum, so the batches are copied side by side on `threads` host threads.
+static int pack_result_parts(fasim_engine* E, const std::vector<const std::vector<HostTriplex>*>& parts, const fasim_scan_stats& st, int threads,
+	fasim_result** out)
+{
+	fasim_result* R = (fasim_result*)calloc(1, sizeof(fasim_result));
+	if (!R) return fail(E, FASIM_E_NOMEM, "out of memory");
+	const size_t np = parts.size();
+	std::vector<size_t> rbase(np + 1, 0), pbase(np + 1, 0);
+	for (size_t k = 0; k < np; k++) {
+		size_t pool = 0;
+		for (const HostTriplex& t : *parts[k]) pool += t.tfo.size() + t.tts.size() + 2;
+		rbase[k + 1] = rbase[k] + parts[k]->size(); pbase[k + 1] = pbase[k] + pool;
+	}
+	const size_t count = rbase[np], pool = pbase[np];
+	R->count = (int64_t)count;
+	R->recs = (fasim_triplex*)malloc(std::max<size_t>(1, count) * sizeof(fasim_triplex));
+	R->pool = (char*)malloc(std::max<size_t>(1, pool));
+	if (!R->recs || !R->pool) { fasim_result_free(R); return fail(E, FASIM_E_NOMEM, "out of memory"); }
+	R->pool_len = (int64_t)pool;
+	if (!pool) R->pool[0] = 0;
+	std::atomic<size_t> next(0);
+	auto work = [&]() {
+		for (;;) {
+			const size_t k = next.fetch_add(1);
+			if (k >= np) break;
+			size_t off = pbase[k];
+			fasim_triplex* dst = R->recs + rbase[k];
+			for (const HostTriplex& t : *parts[k]) {
+				fasim_triplex r;
+				memset(&r, 0, sizeof r);
+				r.stari = t.stari; r.endi = t.endi; r.starj = t.starj; r.endj = t.endj; r.strand = t.strand; r.reverse = t.reverse;
+				r.rule = t.rule; r.nt = t.nt; r.score = t.score; r.identity = t.identity; r.tri_score = t.tri_score; r.seg = t.seg; r.enc = t.enc;
+				r.tfo_off = (int64_t)off; memcpy(R->pool + off, t.tfo.c_str(), t.tfo.size() + 1); off += t.tfo.size() + 1;
+				r.tts_off = (int64_t)off; memcpy(R->pool + off, t.tts.c_str(), t.tts.size() + 1); off += t.tts.size() + 1;
+				*dst++ = r;
+			}
+		}
+	};
+	const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, threads), count > 20000 ? np : 1));
+	if (nt == 1) work();
+	else { std::vector<std::thread> th; for (int k = 0; k < nt; k++) th.emplace_back(work); for (auto& t : th) t.join(); }
+	R->stats = st;
+	*out = R;
+	return FASIM_OK;
+}
+
 static void add_stats(fasim_scan_stats& st, const fasim_scan_stats& x)
 {
 	st.segments += x.segments; st.segments_skipped += x.segments_skipped; st.units += x.units; st.candidates += x.candidates;
@@ -1939,6 +1988,7 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 	const int nenc = (int)encs.size();
 
 	std::vector<std::vector<HostTriplex>> all(nquery);
+	bool packed = false;
 	std::vector<fasim_scan_stats> qst(nquery);
 	for (auto& x : qst) memset(&x, 0, sizeof x);
 	if (seg_count > 0 && nenc > 0) {
@@ -2136,25 +2186,38 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 		if (nq > 0 && E->rna != queries.back()) { int rc = fasim_set_query(E, queries.back().data(), (int)queries.back().size()); if (rc) return rc; }
 		const double t_merge = now_s();
 		std::vector<double> q0(nquery, 1e300), q1(nquery, 0.0);
+		std::vector<std::vector<const std::vector<HostTriplex>*>> parts((size_t)nquery);
 		for (size_t c = 0; c < items.size(); c++) {
 			const int q = items[c].q;
-			for (HostTriplex& t : per_item[c]) all[(size_t)q].push_back(std::move(t));
+			parts[(size_t)q].push_back(&per_item[c]);
 			add_stats(qst[(size_t)q], ist[c]);
 			q0[q] = std::min(q0[q], it0[c]); q1[q] = std::max(q1[q], it1[c]);
 		}
 		// per query: wall clock from the start of its first batch to the end of its last one (neighbouring queries overlap)
 		for (int q = 0; q < nquery; q++) qst[(size_t)q].t_total_s = nquery == 1 ? 0.0 : std::max(0.0, q1[q] - q0[q]);
-		if (g_prof.on) fprintf(stderr, "[fasim prof] scan tail: concatenating the batches              %.3f s\n", now_s() - t_merge);
+		if (nquery == 1) qst[0].t_total_s = now_s() - t_begin;
+		// the records go straight from the batches' lists into the C result (the batches side by side on the host threads);
+		// the lists themselves (half a million strings for a 50 Mb record) are freed behind the caller's back
+		for (int q = 0; q < nquery; q++) {
+			const int rc = pack_result_parts(E, parts[(size_t)q], qst[(size_t)q], E->host_threads_total, &outs[q]);
+			if (rc) { for (int k = 0; k < q; k++) { fasim_result_free(outs[k]); outs[k] = nullptr; } return rc; }
+		}
+		if (nquery == 1) outs[0]->stats.t_total_s = now_s() - t_begin;
+		if (g_prof.on) fprintf(stderr, "[fasim prof] scan tail: packing the records                        %.3f s\n", now_s() - t_merge);
+		if (E->reaper.joinable()) E->reaper.join();
+		E->reaper = std::thread([garbage = std::move(per_item)]() mutable { garbage.clear(); });
+		packed = true;
 	}
 
-	if (nquery == 1) qst[0].t_total_s = now_s() - t_begin;
-	const double t_pack = now_s();
-	for (int q = 0; q < nquery; q++) {
-		const int rc = pack_result(E, all[(size_t)q], qst[(size_t)q], &outs[q]);
-		if (rc) { for (int k = 0; k < q; k++) { fasim_result_free(outs[k]); outs[k] = nullptr; } return rc; }
+	if (!packed) {
+		// (nothing to scan: empty results)
+		if (nquery == 1) qst[0].t_total_s = now_s() - t_begin;
+		for (int q = 0; q < nquery; q++) {
+			const int rc = pack_result(E, all[(size_t)q], qst[(size_t)q], &outs[q]);
+			if (rc) { for (int k = 0; k < q; k++) { fasim_result_free(outs[k]); outs[k] = nullptr; } return rc; }
+		}
+		if (nquery == 1) outs[0]->stats.t_total_s = now_s() - t_begin;
 	}
-	if (nquery == 1) outs[0]->stats.t_total_s = now_s() - t_begin;
-	if (g_prof.on) fprintf(stderr, "[fasim prof] scan tail: packing the records                        %.3f s\n", now_s() - t_pack);
 	if (g_prof.on) {
 		double tot = now_s() - t_begin;
 		fprintf(stderr, "[fasim prof] total %.3f s  stage2 %.3f  stage3 %.3f  host %.3f\n", tot, qst[0].t_stage2_s, qst[0].t_stage3_s, qst[0].t_host_s);
