@@ -35,10 +35,14 @@ namespace {
 
 thread_local std::string g_last_error;     // per thread: the CLI formats and writes outputs on background threads
 
+// device (re)allocations since the process started: hipFree / hipMalloc synchronise the whole device, so a buffer that grows in
+// the middle of a scan stalls every batch in flight (FASIM_PROFILE=1 prints the count per scan)
+static std::atomic<long> g_dev_reallocs{ 0 };
 struct DevBuf {
 	void* p = nullptr; size_t cap = 0;
 	hipError_t ensure(size_t bytes) {
 		if (bytes <= cap) return hipSuccess;
+		g_dev_reallocs.fetch_add(1);
 		if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
 		size_t want = bytes + bytes / 4 + 256;
 		hipError_t e = hipMalloc(&p, want);
@@ -2219,6 +2223,8 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 		if (nquery == 1) outs[0]->stats.t_total_s = now_s() - t_begin;
 	}
 	if (g_prof.on) {
+		static long seen = 0; const long now_r = g_dev_reallocs.load();
+		fprintf(stderr, "[fasim prof] device buffer (re)allocations during this scan: %ld\n", now_r - seen); seen = now_r;
 		double tot = now_s() - t_begin;
 		fprintf(stderr, "[fasim prof] total %.3f s  stage2 %.3f  stage3 %.3f  host %.3f\n", tot, qst[0].t_stage2_s, qst[0].t_stage3_s, qst[0].t_host_s);
 		g_prof.dump();
