@@ -2022,8 +2022,22 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 		static const double guided = [] { const char* e = getenv("FASIM_GUIDED"); return e ? atof(e) : 0.0; }();
 		// FASIM_TAPER=t (percent, default 0): the last t % of the segments go in half-size batches, so that the workers do not
 		// all finish their last batch at the same moment (shorter drain at the end of a scan)
-		static const int taper = [] { const char* e = getenv("FASIM_TAPER"); return e ? atoi(e) : 0; }();
-		const int taper_pct = E->opt_taper >= 0 ? E->opt_taper : taper;
+		static const int taper = [] { const char* e = getenv("FASIM_TAPER"); return e ? atoi(e) : -1; }();
+		int taper_pct = E->opt_taper >= 0 ? E->opt_taper : std::max(0, taper);
+		// Batch size fitted to the record (single-lncRNA scans of >= 128 segments per worker; FASIM_ADAPT=0, an explicit
+		// seg_batch or FASIM_GUIDED switch it off): the segments are cut so that every worker gets R whole rounds of batches
+		// of at most 512 segments (R = the fewest rounds that allow it), and the last quarter of the record goes in half-size
+		// batches.  The workers then neither
+		// idle through a partial last round nor finish their last full-size batch all at once (the drain of a scan is the
+		// stage 3 of its last batches on an otherwise idle GPU): 50 Mb = 10 204 segments -> 15 batches of 511 + 10 of 255,
+		// 2.41 s against 2.61 s with fixed batches of 384 (profiles/r02_ab_batch_shape.txt: the optimum sits exactly where
+		// the batches tile the ten workers, 448 and 576 are both slower than 512; other record sizes: r02_ab_sizes.txt).
+		static const bool adapt = [] { const char* e = getenv("FASIM_ADAPT"); return e ? atoi(e) != 0 : true; }();
+		if (adapt && !envb && E->opt_seg_batch <= 0 && guided <= 0 && nquery == 1 && seg_count >= (int64_t)128 * nworkers) {
+			const int64_t rounds = std::max<int64_t>(1, (seg_count + 512 * (int64_t)nworkers - 1) / (512 * (int64_t)nworkers));
+			seg_batch = std::max<int64_t>(1, std::min<int64_t>((seg_count + rounds * nworkers - 1) / (rounds * nworkers), ((int64_t)8 << 30) / ((int64_t)4 * nenc * tstride)));
+			if (E->opt_taper < 0 && taper < 0) taper_pct = 25;
+		}
 		std::vector<std::pair<int64_t, int64_t>> chunks;
 		{
 			int64_t b0 = seg_first; const int64_t b_end = seg_first + seg_count;
