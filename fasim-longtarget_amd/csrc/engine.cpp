@@ -2042,8 +2042,12 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 		{
 			int64_t b0 = seg_first; const int64_t b_end = seg_first + seg_count;
 			const int64_t taper_from = b_end - seg_count * taper_pct / 100;
+			// FASIM_STAGGER=1 (experiment): the first batch of every worker gets a different size (50 .. 95 % of a full one), so
+			// that the workers do not run their phases in lock step from the start
+			static const bool stagger = [] { const char* e = getenv("FASIM_STAGGER"); return e ? atoi(e) != 0 : false; }();
 			while (b0 < b_end) {
 				int64_t len = (taper_pct > 0 && b0 >= taper_from) ? std::max<int64_t>(1, seg_batch / 2) : seg_batch;
+				if (stagger && (int)chunks.size() < nworkers && seg_batch >= 128) len = seg_batch * (50 + 5 * (int64_t)chunks.size() * 10 / nworkers) / 100;
 				if (guided > 0) {
 					const int64_t g = (int64_t)((double)(b_end - b0) / (guided * nworkers)) + 1;
 					len = std::max<int64_t>(std::min<int64_t>(64, seg_batch), std::min<int64_t>(seg_batch, g));
