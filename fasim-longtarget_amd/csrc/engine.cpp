@@ -2226,8 +2226,21 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 		}
 		if (nquery == 1) outs[0]->stats.t_total_s = now_s() - t_begin;
 		if (g_prof.on) fprintf(stderr, "[fasim prof] scan tail: packing the records                        %.3f s\n", now_s() - t_merge);
+		// Free the batches' lists (half a million strings for a 50 Mb record) here, side by side on the host threads, while the
+		// GPU is idle: left to a background thread (FASIM_REAPER=1) the unmapping runs into the first kernels of the caller's
+		// next scan and stretches them by half (the driver's MMU notifier stalls the queues while the address space changes:
+		// tools/iso_probe.py).
+		static const bool background = [] { const char* e = getenv("FASIM_REAPER"); return e && atoi(e) != 0; }();
 		if (E->reaper.joinable()) E->reaper.join();
-		E->reaper = std::thread([garbage = std::move(per_item)]() mutable { garbage.clear(); });
+		if (background) E->reaper = std::thread([garbage = std::move(per_item)]() mutable { garbage.clear(); });
+		else {
+			std::atomic<size_t> nextf(0);
+			auto freer = [&]() { for (;;) { const size_t c = nextf.fetch_add(1); if (c >= per_item.size()) break; std::vector<HostTriplex>().swap(per_item[c]); } };
+			const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, E->host_threads_total), per_item.size()));
+			if (nt == 1) freer();
+			else { std::vector<std::thread> th; for (int k = 0; k < nt; k++) th.emplace_back(freer); for (auto& t : th) t.join(); }
+		}
+		if (g_prof.on) fprintf(stderr, "[fasim prof] scan tail: packing + freeing the batches' lists        %.3f s\n", now_s() - t_merge);
 		packed = true;
 	}
 
