@@ -12,6 +12,7 @@
 #include <atomic>
 #include <chrono>
 #include <sched.h>
+#include <malloc.h>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -1086,6 +1087,22 @@ int fasim_engine_create(int device, fasim_engine** out)
 	// queues unless told otherwise, which serialises unrelated batches.  Only effective before the runtime initialises
 	// (a host application that touches HIP earlier should export GPU_MAX_HW_QUEUES itself).
 	setenv("GPU_MAX_HW_QUEUES", "8", 0);
+	// Host allocator: every batch builds and drops tables of a few MB on its host threads.  glibc hands such blocks back to the
+	// kernel (munmap / heap trimming), and while the address space of a process with live HIP queues changes, the driver's MMU
+	// notifier holds those queues up (a 120 ms kernel that overlaps the freeing of half a million strings takes 190-250 ms:
+	// tools/iso_probe.py).  Keeping freed blocks of up to 32 MB in the heap removes most of that: 2.42 -> 2.38 s per 50 Mb scan
+	// (profiles/r02_ab_malloc.txt).  Process-wide settings; FASIM_MALLOPT=0 leaves the allocator alone.
+	{
+		static const bool once = [] {
+			const char* e = getenv("FASIM_MALLOPT");
+			if (e && atoi(e) == 0) return false;
+			(void)mallopt(M_MMAP_THRESHOLD, 32 * 1024 * 1024);
+			(void)mallopt(M_TRIM_THRESHOLD, 0x7fffffff);
+			(void)mallopt(M_TOP_PAD, 256 * 1024 * 1024);
+			return true;
+		}();
+		(void)once;
+	}
 	int count = 0;
 	hipError_t he = hipGetDeviceCount(&count);
 	if (he != hipSuccess || count <= 0) return fail(nullptr, FASIM_E_NODEVICE, "no HIP device available (%s); this library has no CPU fallback", hipGetErrorString(he));
