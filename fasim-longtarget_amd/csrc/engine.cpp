@@ -2051,7 +2051,8 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 		// the batches tile the ten workers, 448 and 576 are both slower than 512; other record sizes: r02_ab_sizes.txt).
 		static const bool adapt = [] { const char* e = getenv("FASIM_ADAPT"); return e ? atoi(e) != 0 : true; }();
 		if (adapt && !envb && E->opt_seg_batch <= 0 && guided <= 0 && nquery == 1 && seg_count >= (int64_t)128 * nworkers) {
-			const int64_t rounds = std::max<int64_t>(1, (seg_count + 512 * (int64_t)nworkers - 1) / (512 * (int64_t)nworkers));
+			static const int64_t target = [] { const char* e = getenv("FASIM_BATCH_TARGET"); const int v = e ? atoi(e) : 512; return (int64_t)(v < 64 ? 64 : v); }();
+			const int64_t rounds = std::max<int64_t>(1, (seg_count + target * (int64_t)nworkers - 1) / (target * (int64_t)nworkers));
 			seg_batch = std::max<int64_t>(1, std::min<int64_t>((seg_count + rounds * nworkers - 1) / (rounds * nworkers), ((int64_t)8 << 30) / ((int64_t)4 * nenc * tstride)));
 			if (E->opt_taper < 0 && taper < 0) taper_pct = 25;
 		}
