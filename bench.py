@@ -187,10 +187,12 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    # N ranks share one node's host cores: the engine's default (3/8 of the cores, at most 96 threads for the host side of a
-    # batch) is per process, so divide it among the ranks unless the user has set it
+    # N ranks share one node's host cores.  The host side of a batch (candidates, CIGAR -> record) is a burst that wants about
+    # nine threads per batch in flight (ten batches per rank): with 16 threads per rank a 50 Mb step takes 3.05 s instead of 2.33 s,
+    # 48 -> 2.49 s, 96 or 160 -> 2.33 s, measured on a box with a 16-core share (profiles/r02_ab_hostthreads.txt).  So every rank
+    # keeps six threads per core of its share of the node (at most the single-rank default of 96) unless the user has set it.
     if world > 1 and "FASIM_HOST_THREADS" not in os.environ:
-        os.environ["FASIM_HOST_THREADS"] = str(max(8, min(96, host_cores_uncapped() * 3 // 8 // world)))
+        os.environ["FASIM_HOST_THREADS"] = str(max(16, min(96, 6 * (host_cores_uncapped() // world))))
     mod = entry.load()
     eng = mod.Engine(local)
     rna_path = os.path.join(ROOT, "tests", "golden", "H19.fa")

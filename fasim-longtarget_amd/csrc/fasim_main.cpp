@@ -271,9 +271,10 @@ int main(int argc, char* const* argv)
 		engines.push_back(e);
 	}
 	if (engines.size() > 1 && !getenv("FASIM_HOST_THREADS")) {
-		// one process, several engines: divide the default host-thread budget (3/8 of the cores, at most 96) among them
+		// one process, several engines: every engine keeps six host threads per core of its share of the machine (at most the
+		// single-engine default of 96; the host side of a batch is a burst that wants ~9 threads per batch in flight)
 		const unsigned hc = std::max(1u, std::thread::hardware_concurrency());
-		const int per = std::max(8, (int)std::min(96u, hc * 3 / 8) / (int)engines.size());
+		const int per = std::max(16, (int)std::min(96u, 6 * (hc / (unsigned)engines.size())));
 		for (fasim_engine* e : engines) fasim_set_option(e, "host_threads", per);
 	}
 
