@@ -178,6 +178,17 @@ def main():
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
     if args.share_gpu:
         local = 0
+    # Host threads sleep in stream synchronisation instead of polling (see fasim_engine_create: ten polling threads cost half
+    # of a scan's CPU time).  The flag must be set before the device's context exists, i.e. before torch touches the device.
+    sync_flags = "default (polling)"
+    if os.environ.get("FASIM_BLOCKING_SYNC", "1") != "0":
+        try:
+            import ctypes
+            hip = ctypes.CDLL("libamdhip64.so")
+            if hip.hipSetDevice(local) == 0 and hip.hipSetDeviceFlags(0x4) == 0:      # hipDeviceScheduleBlockingSync
+                sync_flags = "hipDeviceScheduleBlockingSync"
+        except OSError:
+            pass
     torch.cuda.set_device(local)
     xdev = "cuda" if args.backend == "nccl" else "cpu"      # where the exchanged record bytes live
     if world > 1:
@@ -195,6 +206,8 @@ def main():
         os.environ["FASIM_HOST_THREADS"] = str(max(16, min(96, 6 * (host_cores_uncapped() // world))))
     mod = entry.load()
     eng = mod.Engine(local)
+    if os.environ.get("FASIM_DEBUG_SYNCFLAG"):
+        print("[bench] device schedule flags:", sync_flags, file=sys.stderr)
     rna_path = os.path.join(ROOT, "tests", "golden", "H19.fa")
     _, h19 = synth.read_fasta(rna_path)
     rnas = [synth.random_rna(3000, k + 1) for k in range(args.lncrnas)] if args.lncrnas > 0 else [h19]

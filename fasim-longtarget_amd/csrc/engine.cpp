@@ -1107,6 +1107,15 @@ int fasim_engine_create(int device, fasim_engine** out)
 	hipError_t he = hipGetDeviceCount(&count);
 	if (he != hipSuccess || count <= 0) return fail(nullptr, FASIM_E_NODEVICE, "no HIP device available (%s); this library has no CPU fallback", hipGetErrorString(he));
 	if (device < 0 || device >= count) return fail(nullptr, FASIM_E_NODEVICE, "device %d out of range (%d devices)", device, count);
+	{
+		// Host threads SLEEP in hipStreamSynchronize instead of polling: with ten batches in flight ten threads otherwise spin
+		// through a scan -- 12 of the 25 CPU-seconds a 50 Mb scan costs -- on cores the host side of the batches needs (an 8-GPU
+		// node gives each rank a fraction of its cores).  The flag only takes effect before the device's context exists; a host
+		// application that touches HIP first (PyTorch) has to set it itself (bench.py does).  An event created with
+		// hipEventBlockingSync does not have this effect on ROCm 7.2.  FASIM_BLOCKING_SYNC=0 leaves the polling wait.
+		const char* e = getenv("FASIM_BLOCKING_SYNC");
+		if (!(e && atoi(e) == 0)) { (void)hipSetDevice(device); (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); (void)hipGetLastError(); }
+	}
 	fasim_engine* E = new fasim_engine();
 	E->device = device;
 	he = hipSetDevice(device);
