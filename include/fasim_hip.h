@@ -48,6 +48,12 @@ typedef struct fasim_params {
 void fasim_params_default(fasim_params* p);
 
 /* ---- engine ---------------------------------------------------------------------------------- */
+/* Process-wide side effects of the first fasim_engine_create() (each can be switched off by its environment variable):
+ *   GPU_MAX_HW_QUEUES=8 is exported if unset (the batches in flight need their own hardware queues);
+ *   hipSetDeviceFlags(hipDeviceScheduleBlockingSync) for `device`, so that host threads sleep instead of polling in stream
+ *     synchronisation (no effect if the host application created the device's context first; FASIM_BLOCKING_SYNC=0);
+ *   mallopt(): freed host blocks of up to 32 MB stay in the heap instead of being unmapped -- unmapping host memory while HIP
+ *     queues are live stalls the running kernels (FASIM_MALLOPT=0). */
 int  fasim_engine_create(int device, fasim_engine** out);
 void fasim_engine_destroy(fasim_engine* e);
 const char* fasim_last_error(const fasim_engine* e);   /* e may be NULL: last global error */
