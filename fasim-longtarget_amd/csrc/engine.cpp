@@ -59,7 +59,7 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 
 // FASIM_PROFILE=1: wall-clock accumulators of the host phases, printed to stderr at the end of fasim_scan
 struct HostProf {
-	static constexpr int N = 24;
+	static constexpr int N = 32;
 	double t[N] = { 0 }; const char* name[N] = { nullptr };
 	bool on = false;
 	std::mutex mu;
@@ -68,6 +68,8 @@ struct HostProf {
 	void reset() { for (int i = 0; i < N; i++) { t[i] = 0; name[i] = nullptr; } }
 };
 HostProf g_prof;
+static inline double thread_cpu_s() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+struct CpuScope { int i; const char* nm; double t0; CpuScope(int i_, const char* n) : i(i_), nm(n), t0(g_prof.on ? thread_cpu_s() : 0.0) {} ~CpuScope() { if (g_prof.on) g_prof.add(i, nm, thread_cpu_s() - t0); } };
 struct ProfScope { int i; const char* nm; double t0; ProfScope(int i_, const char* n) : i(i_), nm(n), t0(now_s()) {} ~ProfScope() { g_prof.add(i, nm, now_s() - t0); } };
 
 } // namespace
@@ -1689,6 +1691,7 @@ int stage3_range(fasim_engine* E, BatchCtx& C, int ua, int ub, fasim_scan_stats&
 			const int nt = std::max(1, std::min(E->host_threads, (ub - ua) / 256));
 			std::vector<std::vector<CandState>> part(nt);
 			auto work = [&](int ti) {
+				CpuScope cpu(27, "CPU seconds: pick candidates");
 				std::vector<Cand> tmp;
 				const int u0 = ua + (int)((int64_t)(ub - ua) * ti / nt), u1 = ua + (int)((int64_t)(ub - ua) * (ti + 1) / nt);
 				for (int u = u0; u < u1; u++) {
@@ -1846,6 +1849,7 @@ int stage3_range(fasim_engine* E, BatchCtx& C, int ua, int ub, fasim_scan_stats&
 			for (int u = ua; u < ub; u++) first[u + 1] += first[u];
 			std::atomic<int> next(ua);
 			auto work = [&]() {
+				CpuScope cpu(26, "CPU seconds: records (convert_triplex, dedup)");
 				for (;;) {
 					const int u = next.fetch_add(1);
 					if (u >= ub) break;
@@ -2154,6 +2158,7 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 			if (R.pending.fetch_sub(1) == 1) { std::lock_guard<std::mutex> lk(pool_mu); pool_cv.notify_all(); }
 		};
 		auto run = [&](size_t wi) {
+			CpuScope cpu(28, "CPU seconds: worker threads themselves (HIP calls, lists, decisions)");
 			(void)hipSetDevice(E->device);
 			fasim_engine* w = ws[wi];
 			for (;;) {

@@ -165,6 +165,13 @@ bool only_acgtn(const char* seg, int n)
 void convert_triplex(const AlignResult& al, const uint32_t* cigar, const std::string& rna, const char* seg, int n, int enc,
 	long dna_start, const fasim_params& p, std::vector<HostTriplex>& list, bool seg_acgtn, bool with_strings)
 {
+	// the alignment's length is the sum of its CIGAR runs: one shorter than -ni never becomes a record (the check further
+	// down, fastsim.h:385), so its strings, identity and stability need not be worked out
+	{
+		int64_t total = 0;
+		for (int k = 0; k < al.cigar_len; k++) total += cigar[k] >> 4;
+		if (total < p.ntMin) return;
+	}
 	const EncInfo e = enc_info(enc);
 	const char* o = kRuleOut[enc];
 	// complement() drops letters outside ACGTN (rules.h:82-83); only then the display strand has to be
