@@ -1850,6 +1850,8 @@ int stage3_range(fasim_engine* E, BatchCtx& C, int ua, int ub, fasim_scan_stats&
 			std::atomic<int> next(ua);
 			auto work = [&]() {
 				CpuScope cpu(26, "CPU seconds: records (convert_triplex, dedup)");
+				std::vector<TriplexNum> mine, kept;
+				std::vector<HostTriplex> one;
 				for (;;) {
 					const int u = next.fetch_add(1);
 					if (u >= ub) break;
@@ -1857,7 +1859,7 @@ int stage3_range(fasim_engine* E, BatchCtx& C, int ua, int ub, fasim_scan_stats&
 					const int s = u / nenc, enc = encs[u % nenc];
 					const char* seg = dna + sidx[s] * step;
 					const long dna_start = (long)(sidx[s] * step);
-					std::vector<HostTriplex> mine;
+					mine.clear(); kept.clear();
 					const bool acgtn = seg_acgtn[s] != 0;
 					for (size_t k = first[u]; k < first[u + 1]; k++) {
 						CandState& x = cs[k];
@@ -1865,21 +1867,21 @@ int stage3_range(fasim_engine* E, BatchCtx& C, int ua, int ub, fasim_scan_stats&
 						if (al.sw_score == 0) continue;                                                    // fastsim.h:253
 						al.ref_begin += x.c.pos - cut + 1; al.ref_end += x.c.pos - cut + 1;                // :254-255
 						const size_t before = mine.size();
-						convert_triplex(al, cigars.data() + al.cigar_off, E->rna, seg, slen[s], enc, dna_start, p, mine, acgtn, false);
+						convert_triplex_num(al, cigars.data() + al.cigar_off, E->rna, seg, slen[s], enc, dna_start, p, mine, acgtn);
 						if (mine.size() > before) mine.back().cand = (int)k;
 					}
-					dedup_top(mine, p, per_unit[u]);
-					std::vector<HostTriplex> one;
-					for (HostTriplex& t : per_unit[u]) {
-						t.seg = (int)sidx[s]; t.enc = enc;
-						if (!(t.score >= p.scoreMin && t.identity >= p.minIdentity && t.tri_score >= p.minStability && t.nt >= p.cLength)) continue;   // dropped below anyway
-						// the TFO / TTS strings of a surviving record: same conversion once more, this time keeping them
-						const CandState& x = cs[(size_t)t.cand];
+					dedup_top_num(mine, p, kept);
+					for (const TriplexNum& tn : kept) {
+						// LongTarget()'s tail filter (Fasim-LongTarget.cpp:589-597): what it drops is dropped here already
+						if (!(tn.score >= p.scoreMin && tn.identity >= p.minIdentity && tn.tri_score >= p.minStability && tn.nt >= p.cLength)) continue;
+						// a surviving record: the same conversion once more, this time with its TFO / TTS strings
+						const CandState& x = cs[(size_t)tn.cand];
 						AlignResult al = x.al;
 						al.ref_begin += x.c.pos - x.cut + 1; al.ref_end += x.c.pos - x.cut + 1;
 						one.clear();
 						convert_triplex(al, cigars.data() + al.cigar_off, E->rna, seg, slen[s], enc, dna_start, p, one, acgtn, true);
-						t.tfo.swap(one[0].tfo); t.tts.swap(one[0].tts);
+						one[0].seg = (int)sidx[s]; one[0].enc = enc; one[0].cand = tn.cand;
+						per_unit[u].push_back(std::move(one[0]));
 					}
 				}
 			};

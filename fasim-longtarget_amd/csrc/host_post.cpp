@@ -185,8 +185,19 @@ void convert_triplex(const AlignResult& al, const uint32_t* cigar, const std::st
 		const char c = seg[e.reversed ? n - 1 - q : q];
 		return e.strand == 1 ? comp_letter(c) : c;
 	};
+	if (!with_strings) {
+		std::vector<TriplexNum> one;
+		convert_triplex_num(al, cigar, rna, seg, n, enc, dna_start, p, one, seg_acgtn);
+		if (one.empty()) return;
+		HostTriplex t;
+		t.stari = one[0].stari; t.endi = one[0].endi; t.starj = one[0].starj; t.endj = one[0].endj;
+		t.strand = e.strand; t.reverse = e.para; t.rule = e.rule; t.nt = one[0].nt;
+		t.score = one[0].score; t.identity = one[0].identity; t.tri_score = one[0].tri_score;
+		list.push_back(std::move(t));
+		return;
+	}
 	// expand the CIGAR from (ref_begin, query_begin): M -> (target, src, rna); I -> ('-','-',rna); D -> (target, src,'-')
-	// (per-thread buffers: this runs for every candidate alignment, ~10^6 times per 2.5 Mb of DNA)
+	// (per-thread buffers)
 	thread_local std::string tgt_al, tts, tfo;
 	tgt_al.clear(); tts.clear(); tfo.clear();
 	int q = al.ref_begin, r = al.query_begin;
@@ -236,37 +247,100 @@ void convert_triplex(const AlignResult& al, const uint32_t* cigar, const std::st
 	list.push_back(std::move(t));
 }
 
+// The numbers only (every candidate alignment of a scan goes through here; the strings are built for the ~1 % that survive
+// all filters): one walk over the CIGAR, the same comparisons and the same left-to-right float accumulation as above.
+void convert_triplex_num(const AlignResult& al, const uint32_t* cigar, const std::string& rna, const char* seg, int n, int enc,
+	long dna_start, const fasim_params& p, std::vector<TriplexNum>& list, bool seg_acgtn)
+{
+	int64_t total = 0;
+	for (int k = 0; k < al.cigar_len; k++) total += cigar[k] >> 4;
+	if (total < p.ntMin) return;                                       // fastsim.h:385
+	const EncInfo e = enc_info(enc);
+	const char* o = kRuleOut[enc];
+	const bool clean = seg_acgtn || e.strand != 1;
+	std::string src;
+	if (!clean) make_src(seg, n, true, e.reversed, src);
+	auto src_at = [&](int q) -> char {
+		if (!clean) return (q >= 0 && q < (int)src.size()) ? src[q] : '\0';
+		if (q < 0 || q >= n) return '\0';
+		const char c = seg[e.reversed ? n - 1 - q : q];
+		return e.strand == 1 ? comp_letter(c) : c;
+	};
+	const int nt = (int)total;
+	const bool want_tri = nt >= p.ntMin && nt <= p.ntMax;
+	int match = 0, mis = 0;
+	float tri = 0.0f, prev_v = 0.0f, v = 0.0f;
+	char prev_c = 0, cur = 0;
+	int q = al.ref_begin, r = al.query_begin;
+	for (int k = 0; k < al.cigar_len; k++) {
+		const uint32_t len = cigar[k] >> 4, op = cigar[k] & 0xf;
+		for (uint32_t t = 0; t < len; t++) {
+			char tgt, tt, tf;
+			if (op == 1) { tgt = '-'; tt = '-'; tf = rna[r++]; }
+			else {
+				tgt = (q >= 0 && q < n) ? map_base(o, seg[e.reversed ? n - 1 - q : q]) : '\0';
+				tt = src_at(q);
+				q++;
+				tf = (op == 2) ? '-' : rna[r++];
+			}
+			if (tgt == tf) match++; else mis++;
+			if (want_tri) {
+				cur = (tgt == '-') ? '-' : tt;
+				v = triplex_stability(cur, tf, e.para);
+				if (cur == prev_c && cur == 'T') { tri = tri - prev_v + p.penaltyT; v = p.penaltyT; }
+				if (cur == prev_c && cur == 'C') { tri = tri - prev_v + p.penaltyC; v = p.penaltyC; }
+				prev_v = v;
+				if (tgt != '-') prev_c = cur;
+				tri += v;
+			}
+		}
+	}
+	TriplexNum t;
+	t.identity = (float)(100 * match) / (float)(match + mis);            // fastsim.h:335
+	if (want_tri) tri = tri / nt;
+	int rs, re;
+	if ((e.para > 0 && e.strand == 1) || (e.para < 0 && e.strand == 0)) { rs = n - al.ref_end - 1; re = n - al.ref_begin - 1; }   // fastsim.h:389-396
+	else { rs = al.ref_begin + 1; re = al.ref_end + 1; }
+	t.stari = al.query_begin + 1; t.endi = al.query_end + 1;
+	t.starj = (int)(rs + dna_start); t.endj = (int)(re + dna_start);
+	t.nt = nt; t.cand = -1;
+	t.score = (float)al.sw_score; t.tri_score = tri;
+	list.push_back(t);
+}
+
 // ---- a14 (fastsim.h:92-156, 273-288).  The comparators are not strict weak orderings; the order that
 // comes out is whatever libstdc++'s std::sort/std::unique produce for this comparison sequence, so we
 // call exactly those algorithms on the same input order.
-static bool by_start(const HostTriplex& a, const HostTriplex& b)
+template <class T> static bool by_start(const T& a, const T& b)
 {
 	if (a.stari == b.stari) return a.starj == b.starj ? a.score > b.score : a.starj > b.starj;
 	return a.starj > b.starj;
 }
-static bool by_end(const HostTriplex& a, const HostTriplex& b)
+template <class T> static bool by_end(const T& a, const T& b)
 {
 	if (a.endi == b.endi) return a.starj == b.starj ? a.score > b.score : a.starj < b.starj;
 	return a.starj < b.starj;
 }
-static bool by_score(const HostTriplex& a, const HostTriplex& b) { return a.score > b.score; }
-static bool redundant(const HostTriplex& a, const HostTriplex& b)
+template <class T> static bool by_score(const T& a, const T& b) { return a.score > b.score; }
+template <class T> static bool redundant(const T& a, const T& b)
 {
 	if (a.stari == b.stari && a.starj == b.starj && a.endi == b.endi && a.endj == b.endj && a.score == b.score) return true;
 	return b.stari >= a.stari && b.starj >= a.starj && b.endi <= a.endi && b.endj <= a.endj && b.score < a.score;
 }
 
-void dedup_top(std::vector<HostTriplex>& mine, const fasim_params& p, std::vector<HostTriplex>& out)
+template <class T> static void dedup_top_t(std::vector<T>& mine, const fasim_params& p, std::vector<T>& out)
 {
-	std::sort(mine.begin(), mine.end(), by_start);
-	mine.erase(std::unique(mine.begin(), mine.end(), redundant), mine.end());
-	std::sort(mine.begin(), mine.end(), by_end);
-	mine.erase(std::unique(mine.begin(), mine.end(), redundant), mine.end());
-	std::sort(mine.begin(), mine.end(), by_score);
+	std::sort(mine.begin(), mine.end(), by_start<T>);
+	mine.erase(std::unique(mine.begin(), mine.end(), redundant<T>), mine.end());
+	std::sort(mine.begin(), mine.end(), by_end<T>);
+	mine.erase(std::unique(mine.begin(), mine.end(), redundant<T>), mine.end());
+	std::sort(mine.begin(), mine.end(), by_score<T>);
 	const size_t lim = mine.size() > 50 ? 50 : mine.size();
 	for (size_t i = 0; i < lim; i++)
 		if (mine[i].identity >= p.minIdentity && mine[i].tri_score >= p.minStability && mine[i].nt >= p.ntMin) out.push_back(mine[i]);
 }
+void dedup_top(std::vector<HostTriplex>& mine, const fasim_params& p, std::vector<HostTriplex>& out) { dedup_top_t(mine, p, out); }
+void dedup_top_num(std::vector<TriplexNum>& mine, const fasim_params& p, std::vector<TriplexNum>& out) { dedup_top_t(mine, p, out); }
 
 // ---- a16: cluster_triplex (Fasim-LongTarget.cpp:600-691) --------------------------------------------
 // Same sequential semantics with flat arrays instead of std::map<size_t, axis>.  The reference's class

@@ -55,6 +55,15 @@ void sim_finish_unit(const std::string& rna, const std::string& target, const st
 // tail of fastSIM (fastsim.h:273-288): sort/unique/sort/unique/sort, top 50, identity/stability/nt filter
 void dedup_top(std::vector<HostTriplex>& mine, const fasim_params& p, std::vector<HostTriplex>& out);
 
+// The numbers of a record only (what the dedup and the filters look at), trivially copyable: the scan runs every candidate
+// alignment (~3 * 10^7 per 50 Mb) through convert_triplex_num / dedup_top_num and builds a HostTriplex with its strings only
+// for the survivors.  std::sort / std::unique make the same sequence of comparisons whatever the element type, so the
+// (comparator-dependent) order is the one the HostTriplex version produces.
+struct TriplexNum { int stari, endi, starj, endj, nt, cand; float score, identity, tri_score; };
+void convert_triplex_num(const AlignResult& al, const uint32_t* cigar, const std::string& rna, const char* seg, int n, int enc,
+	long dna_start, const fasim_params& p, std::vector<TriplexNum>& list, bool seg_acgtn);
+void dedup_top_num(std::vector<TriplexNum>& mine, const fasim_params& p, std::vector<TriplexNum>& out);
+
 void cluster_triplex(int dd, int length, std::vector<HostTriplex>& list);
 std::string tfosorted_text(std::vector<HostTriplex>& list, const std::string& chr, long start_genome, const fasim_params& p);
 // bedGraph of one class (print_cluster); `list` must have been clustered (tfosorted_text or cluster_triplex)
