@@ -98,8 +98,11 @@ struct fasim_engine {
 	HeavyGate own_gate;
 	HeavyGate* gate = nullptr;            // shared by the workers of one fasim_scan (points at the parent's own_gate)
 	int host_threads_total = 1;
+	int host_threads_share_total = 1;            // (workers) the scan's total, for the share of a worker near the end of a scan
 	bool host_threads_explicit = false;          // FASIM_HOST_THREADS / option host_threads given: -F keeps to it too
 	std::thread reaper;                          // frees the host lists of the previous scan in the background
+	std::atomic<int>* active_workers = nullptr;  // (set for the duration of a scan) workers that still have batches: the host threads of
+	                                             // those that have run out go to the bursts of the others
 	int sim_threads = 1;                         // -F: host threads of this worker for the finish half (all cores shared by the batches in flight)
 	int opt_workers = 0, opt_seg_batch = 0;      // fasim_set_option overrides (0 = default / environment)
 	int opt_taper = -1, opt_gate = -1;           // (-1 = default / environment)
@@ -1885,7 +1888,9 @@ int stage3_range(fasim_engine* E, BatchCtx& C, int ua, int ub, fasim_scan_stats&
 					}
 				}
 			};
-			const int nt = std::max(1, std::min(E->host_threads, ub - ua));
+			int share = E->host_threads;
+			if (E->active_workers) { const int act = std::max(1, E->active_workers->load()); share = std::max(share, std::min(32, E->host_threads_share_total / act)); }
+			const int nt = std::max(1, std::min(share, ub - ua));
 			if (nt == 1) work();
 			else { std::vector<std::thread> th; for (int k = 0; k < nt; k++) th.emplace_back(work); for (auto& t : th) t.join(); }
 		}
@@ -2078,8 +2083,12 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 			// FASIM_STAGGER=1 (experiment): the first batch of every worker gets a different size (50 .. 95 % of a full one), so
 			// that the workers do not run their phases in lock step from the start
 			static const bool stagger = [] { const char* e = getenv("FASIM_STAGGER"); return e ? atoi(e) != 0 : false; }();
+			// FASIM_TAPER2=t (experiment): the very last t % of the segments in quarter-size batches
+			static const int taper2 = [] { const char* e = getenv("FASIM_TAPER2"); return e ? atoi(e) : 0; }();
+			const int64_t taper2_from = b_end - seg_count * taper2 / 100;
 			while (b0 < b_end) {
 				int64_t len = (taper_pct > 0 && b0 >= taper_from) ? std::max<int64_t>(1, seg_batch / 2) : seg_batch;
+				if (taper2 > 0 && b0 >= taper2_from && seg_batch >= 256) len = std::max<int64_t>(1, seg_batch / 4);
 				if (stagger && (int)chunks.size() < nworkers && seg_batch >= 128) len = seg_batch * (50 + 5 * (int64_t)chunks.size() * 10 / nworkers) / 100;
 				if (guided > 0) {
 					const int64_t g = (int64_t)((double)(b_end - b0) / (guided * nworkers)) + 1;
@@ -2101,6 +2110,7 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 			int rc = fasim_engine_create(E->device, &w); if (rc) return fail(E, rc, "cannot create worker engine: %s", fasim_last_error(nullptr));
 			E->workers.push_back(w);
 		}
+		std::atomic<int> active_workers(nworkers);
 		std::vector<fasim_engine*> ws(1, E);
 		for (int k = 0; k < nworkers - 1; k++) ws.push_back(E->workers[k]);
 		{
@@ -2112,6 +2122,7 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 			w->scan_v1 = E->scan_v1; w->align_v1 = E->align_v1;
 			w->hz_chunks = E->hz_chunks; w->hz_snap = E->hz_snap; w->hz_target = E->hz_target; w->hz_hot_w = E->hz_hot_w;
 			w->host_threads = std::max(1, E->host_threads_total / nworkers);
+			w->host_threads_share_total = E->host_threads_total; w->active_workers = &active_workers;
 			{
 				// -F: the finish half of classic SIM is ~40 ms of host work per unit and nothing else needs the cores meanwhile
 				const int all = E->host_threads_explicit ? E->host_threads_total : usable_cores();
@@ -2163,8 +2174,10 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 			CpuScope cpu(28, "CPU seconds: worker threads themselves (HIP calls, lists, decisions)");
 			(void)hipSetDevice(E->device);
 			fasim_engine* w = ws[wi];
+			bool retired = false;
 			for (;;) {
 				const size_t c = next.fetch_add(1);
+				if (c >= items.size() && !retired) { retired = true; active_workers.fetch_sub(1); }
 				if (c >= items.size()) {
 					// out of items: help with published stage-3 sub-tasks until every item is finished
 					SubTask t{ 0, 0, 0 }; bool have = false;
@@ -2236,6 +2249,7 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 		const double t_workers = now_s();
 		if (ws.size() == 1) run(0);
 		else { std::vector<std::thread> th; for (size_t wi = 0; wi < ws.size(); wi++) th.emplace_back(run, wi); for (auto& t : th) t.join(); }
+		for (fasim_engine* w : ws) w->active_workers = nullptr;
 		if (g_prof.on) fprintf(stderr, "[fasim prof] scan workers                                  %.3f s\n", now_s() - t_workers);
 		for (size_t wi = 0; wi < ws.size(); wi++) if (wrc[wi]) { if (ws[wi] != E) E->err = ws[wi]->err; return wrc[wi]; }
 		// a multi-query call leaves the engine on its LAST query (documented in fasim_hip.h)
