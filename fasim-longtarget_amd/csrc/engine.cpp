@@ -1385,6 +1385,55 @@ int fasim_sim_forward_batch(fasim_engine* E, const char* targets, const int64_t*
 	return FASIM_OK;
 }
 
+int fasim_selfcheck_records(uint64_t seed, int32_t n, int32_t* mismatches)
+{
+	if (!mismatches || n <= 0) return fail(nullptr, FASIM_E_ARG, "bad arguments");
+	uint64_t x = seed ? seed : 1;
+	auto rnd = [&]() { x += 0x9E3779B97F4A7C15ull; uint64_t z = x; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
+	const char letters[] = "ACGTACGTACGTNacgt";
+	std::string seg(5000, 'A'), rna(3000, 'A');
+	for (char& c : seg) c = letters[rnd() % (sizeof letters - 1)];
+	for (char& c : rna) c = "ACGU"[rnd() % 4];
+	fasim_params p; fasim_params_default(&p);
+	int bad = 0;
+	const bool acgtn = false;
+	std::vector<HostTriplex> hs; std::vector<TriplexNum> ns;
+	for (int k = 0; k < n; k++) {
+		// a random alignment: a few runs of M / I / D inside the segment and the lncRNA
+		AlignResult al; memset(&al, 0, sizeof al);
+		uint32_t cig[16]; int nc = 1 + (int)(rnd() % 6), ref = 0, qry = 0;
+		for (int c = 0; c < nc; c++) { const uint32_t op = c % 2 == 0 ? 0u : 1u + (uint32_t)(rnd() % 2), len = 1 + (uint32_t)(rnd() % (op == 0 ? 40 : 3)); cig[c] = (len << 4) | op; if (op != 1) ref += (int)len; if (op != 2) qry += (int)len; }
+		al.cigar_off = 0; al.cigar_len = nc; al.sw_score = 20 + (int)(rnd() % 200);
+		al.ref_begin = (int)(rnd() % (uint64_t)(5000 - ref)); al.ref_end = al.ref_begin + ref - 1;
+		al.query_begin = (int)(rnd() % (uint64_t)(3000 - qry)); al.query_end = al.query_begin + qry - 1;
+		const int enc = (int)(rnd() % 48);
+		std::vector<HostTriplex> a, b; std::vector<TriplexNum> c;
+		convert_triplex(al, cig, rna, seg.data(), 5000, enc, 1000, p, a, acgtn, true);
+		convert_triplex(al, cig, rna, seg.data(), 5000, enc, 1000, p, b, acgtn, false);
+		convert_triplex_num(al, cig, rna, seg.data(), 5000, enc, 1000, p, c, acgtn);
+		if (a.size() != b.size() || a.size() != c.size()) { bad++; continue; }
+		if (a.empty()) continue;
+		const HostTriplex& s1 = a[0]; const HostTriplex& s2 = b[0]; const TriplexNum& s3 = c[0];
+		auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+		if (s1.stari != s3.stari || s1.endi != s3.endi || s1.starj != s3.starj || s1.endj != s3.endj || s1.nt != s3.nt || bits(s1.score) != bits(s3.score) ||
+			bits(s1.identity) != bits(s3.identity) || bits(s1.tri_score) != bits(s3.tri_score) || bits(s2.identity) != bits(s1.identity) || bits(s2.tri_score) != bits(s1.tri_score)) bad++;
+		// the same record, squeezed into a small coordinate range so that the dedup sees ties, containments and equal scores
+		HostTriplex h = s2; h.stari = 1 + (int)(rnd() % 6); h.endi = h.stari + (int)(rnd() % 6); h.starj = 100 + (int)(rnd() % 6); h.endj = h.starj + (int)(rnd() % 6);
+		h.score = (float)(50 + rnd() % 4); h.cand = k;
+		TriplexNum t; t.stari = h.stari; t.endi = h.endi; t.starj = h.starj; t.endj = h.endj; t.nt = h.nt; t.cand = k; t.score = h.score; t.identity = h.identity; t.tri_score = h.tri_score;
+		hs.push_back(h); ns.push_back(t);
+		if (hs.size() == 40 || k == n - 1) {
+			std::vector<HostTriplex> oh; std::vector<TriplexNum> on;
+			dedup_top(hs, p, oh); dedup_top_num(ns, p, on);
+			if (oh.size() != on.size()) bad++;
+			else for (size_t i = 0; i < oh.size(); i++) if (oh[i].cand != on[i].cand) bad++;
+			hs.clear(); ns.clear();
+		}
+	}
+	*mismatches = bad;
+	return FASIM_OK;
+}
+
 int fasim_pick_candidates(const int32_t* cols, int32_t n, int32_t threshold, int32_t* out_score, int32_t* out_pos,
 	int32_t cap, int32_t* count)
 {

@@ -91,6 +91,11 @@ int fasim_ssw_colmax_word(fasim_engine* e, const char* target, int32_t n, int32_
 /* peak picking of Aligner::preAlign (ssw_cpp.cpp:427-572) on a column-max array (host logic).     */
 int fasim_pick_candidates(const int32_t* cols, int32_t n, int32_t threshold,
                           int32_t* out_score, int32_t* out_pos, int32_t cap, int32_t* count);
+/* Self-check of the host record path (pure host code, no device): `n` random alignments (random CIGARs over a random segment
+ * and lncRNA, every rule encoding) through the numbers-only conversion the scan uses and through the reference-shaped
+ * string conversion, then both record types through the dedup (sort / unique with the reference's comparators, which are
+ * not strict weak orderings: the order must match exactly).  *mismatches = number of differences (0 expected).          */
+int fasim_selfcheck_records(uint64_t seed, int32_t n, int32_t* mismatches);
 /* ssw_align() (ssw.h:118, sswNew.cpp:1446) behind Aligner::Align (ssw_cpp.cpp:599-643).           */
 typedef struct fasim_alignment {
 	int32_t sw_score, ref_begin, ref_end, query_begin, query_end;

@@ -234,3 +234,17 @@ def test_tfoclass_writer_from_reference_rows(golden_dir, stem, hdr, n, lg, name)
     for level in (1, 2):
         got = mod.tfoclass(res, level, chro, start, n, name, p)
         assert got == open(os.path.join(golden_dir, f"{stem}.TFOclass{level}"), "rb").read()
+
+
+def test_host_record_path_selfcheck():
+    """The scan's numbers-only record conversion and its trivially copyable records through the dedup give what the
+    reference-shaped string conversion and the full records give (float bits, order under the reference's comparators)."""
+    import ctypes as C
+    m = _mod()
+    L = m.lib()
+    L.fasim_selfcheck_records.restype = C.c_int
+    L.fasim_selfcheck_records.argtypes = [C.c_uint64, C.c_int32, C.POINTER(C.c_int32)]
+    for seed in (1, 2, 3):
+        bad = C.c_int32(-1)
+        assert L.fasim_selfcheck_records(seed, 20000, C.byref(bad)) == 0
+        assert bad.value == 0, seed
