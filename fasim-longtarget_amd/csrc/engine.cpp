@@ -2119,13 +2119,22 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 		// 2.41 s against 2.61 s with fixed batches of 384 (profiles/r02_ab_batch_shape.txt: the optimum sits exactly where
 		// the batches tile the ten workers, 448 and 576 are both slower than 512; other record sizes: r02_ab_sizes.txt).
 		static const bool adapt = [] { const char* e = getenv("FASIM_ADAPT"); return e ? atoi(e) != 0 : true; }();
-		if (adapt && !envb && E->opt_seg_batch <= 0 && guided <= 0 && nquery == 1 && seg_count >= (int64_t)128 * nworkers) {
+		// (a batch of several lncRNAs is one stream of items, lncRNA after lncRNA, and keeps fixed batches of 384: with
+		//  FASIM_ADAPT_MULTI=1 -- the fitted batch size for all of them, the tapered quarter in the last one -- config 4 in small
+		//  is 2 % slower, tools/ab_cfg4.sh)
+		static const bool adapt_multi = [] { const char* e = getenv("FASIM_ADAPT_MULTI"); return e ? atoi(e) != 0 : false; }();
+		bool taper_last_only = false;
+		if (adapt && !envb && E->opt_seg_batch <= 0 && guided <= 0 && (nquery == 1 || adapt_multi) && seg_count >= (int64_t)128 * nworkers) {
+			taper_last_only = nquery > 1;
 			static const int64_t target = [] { const char* e = getenv("FASIM_BATCH_TARGET"); const int v = e ? atoi(e) : 512; return (int64_t)(v < 64 ? 64 : v); }();
 			const int64_t rounds = std::max<int64_t>(1, (seg_count + target * (int64_t)nworkers - 1) / (target * (int64_t)nworkers));
 			seg_batch = std::max<int64_t>(1, std::min<int64_t>((seg_count + rounds * nworkers - 1) / (rounds * nworkers), ((int64_t)8 << 30) / ((int64_t)4 * nenc * tstride)));
 			if (E->opt_taper < 0 && taper < 0) taper_pct = 25;
 		}
-		std::vector<std::pair<int64_t, int64_t>> chunks;
+		std::vector<std::pair<int64_t, int64_t>> chunks, chunks_plain;
+		if (taper_last_only) {
+			for (int64_t b0 = seg_first, b_end = seg_first + seg_count; b0 < b_end; ) { const int64_t len = std::min(seg_batch, b_end - b0); chunks_plain.push_back({ b0, b0 + len }); b0 += len; }
+		}
 		{
 			int64_t b0 = seg_first; const int64_t b_end = seg_first + seg_count;
 			const int64_t taper_from = b_end - seg_count * taper_pct / 100;
@@ -2151,7 +2160,7 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 		struct Item { int q; int64_t b0, b1; };
 		std::vector<Item> items;
 		items.reserve(chunks.size() * (size_t)nquery);
-		for (int q = 0; q < nquery; q++) for (const auto& c : chunks) items.push_back({ q, c.first, c.second });
+		for (int q = 0; q < nquery; q++) for (const auto& c : (taper_last_only && q + 1 < nquery) ? chunks_plain : chunks) items.push_back({ q, c.first, c.second });
 		nworkers = (int)std::min<size_t>((size_t)nworkers, items.size());
 		// worker 0 is this engine; the others are lazily created engines on the same device
 		while ((int)E->workers.size() < nworkers - 1) {
