@@ -61,9 +61,10 @@ class ScanStats(C.Structure):
                 ("align_calls", C.c_int64), ("align_word_reruns", C.c_int64), ("stage2_overflow_units", C.c_int64),
                 ("stage1_word_reruns", C.c_int64), ("logical_cells", C.c_int64), ("t_total_s", C.c_double),
                 ("t_stage1_s", C.c_double), ("t_stage2_s", C.c_double), ("t_stage3_s", C.c_double), ("t_host_s", C.c_double),
-                ("kernel_ms", C.c_double * 8), ("kernel_launches", C.c_int64 * 8), ("cells_stage1", C.c_int64),
+                ("kernel_ms", C.c_double * 10), ("kernel_launches", C.c_int64 * 10), ("cells_stage1", C.c_int64),
                 ("cells_stage2", C.c_int64), ("cells_stage3", C.c_int64), ("hazard_units", C.c_int64), ("rev_exact", C.c_int64),
-                ("exact_replays", C.c_int64), ("tries_skipped", C.c_int64)]
+                ("exact_replays", C.c_int64), ("tries_skipped", C.c_int64), ("band_tries", C.c_int64), ("band_proven", C.c_int64),
+                ("band_cells", C.c_int64)]
 
 
 class SimNode(C.Structure):

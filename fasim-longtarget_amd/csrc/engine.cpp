@@ -123,8 +123,14 @@ struct fasim_engine {
 	struct Timed { hipEvent_t a, b; int family; };
 	std::vector<Timed> timed;
 	std::vector<hipEvent_t> ev_pool;
-	double kernel_ms[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-	int64_t kernel_launches[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	double kernel_ms[FASIM_KERNEL_FAMILIES] = { 0 };
+	int64_t kernel_launches[FASIM_KERNEL_FAMILIES] = { 0 };
+	// banded stage 3 (band.hip): block maxima left by the last main k_scan pass of this engine, lists and column streams of the
+	// tries selected per band class
+	DevBuf ublk, btarget, bidx, bcounts, blist[3], bslots[3];
+	int ublk_units = 0, ublk_blocks = 0;         // units covered by `ublk` (0: none), blocks per (unit, tile)
+	const uint32_t* ub_view = nullptr;           // (as tc_view) the block maxima of the batch's owner during a stolen sub-task
+	int opt_band = -1;                           // option "band": 0 off, 1 on (-1 = default / environment FASIM_BAND)
 };
 
 namespace {
@@ -327,6 +333,16 @@ static int usable_cores()
 		fclose(f);
 	}
 	return std::max(1, n);
+}
+
+// Banded stage 3 (band.hip): classes usable for the current query; 0 = off (FASIM_BAND=0 / option band = 0, stripe-faithful
+// modes, queries the band kernel does not hold)
+static int band_mask(const fasim_engine* E)
+{
+	static const int env = [] { const char* e = getenv("FASIM_BAND"); return e ? atoi(e) : 1; }();
+	const int on = E->opt_band >= 0 ? E->opt_band : env;
+	if (!on || E->align_v1 || E->scan_v1) return 0;
+	return band_classes(E->m);
 }
 
 // FASIM_HAZARD_CHUNKS=0: whole-unit re-run of the hazard units (the round-1 path); FASIM_HAZARD_SNAP=0: the checkpoint pass
@@ -563,6 +579,14 @@ int run_scan_v2(fasim_engine* E, const UnitBatch& B, const std::vector<char>& un
 				L.snap = E->snap.as<uint32_t>(); L.snap_per_unit = spu; E->snap_units = nu; E->snap_per_unit = spu;
 			} else (void)hipGetLastError();
 		}
+	}
+	// block maxima for the banded stage 3 (only the main pass, whose scoring is the stage-2/3 one, leaves them)
+	E->ublk_units = 0; E->ublk_blocks = 0;
+	if (band_mask(E)) {
+		const int nb = scan_ublk_blocks(B.tstride);
+		if (E->ublk.ensure((size_t)nu * systolic_tiles(E->m) * nb * 64 * sizeof(uint32_t)) == hipSuccess) {
+			L.ublk = E->ublk.as<uint32_t>(); L.ublk_blocks = nb; E->ublk_units = nu; E->ublk_blocks = nb;
+		} else (void)hipGetLastError();
 	}
 	if (E->st_heavy != E->st) HIPOK(hipStreamSynchronize(E->st));      // k_encode and the memset above ran on the other stream
 	{
@@ -889,6 +913,92 @@ int run_fwd_both(fasim_engine* E, const UnitBatch& B, const std::vector<WindowPr
 	return FASIM_OK;
 }
 
+// Banded forward pass (band.hip).  For every try k with target score target[k] (what the try is expected to reach) k_band_select
+// picks a row band and the score theta_min from which the band's result is provably the full-height result; k_align_band runs
+// the bands; a try whose band came back below its theta_min gets a second band chosen for the score it did reach (a lower
+// bound of the true score).  On return fo[k].flags & 24 marks the tries that still need the full-height kernel.
+int run_fwd_band(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, const std::vector<int32_t>& target,
+	std::vector<FwdOut>& fo, fasim_scan_stats* st)
+{
+	const int n = (int)W.size();
+	fo.resize(n);
+	if (!n) return FASIM_OK;
+	ProfScope ps(28, "run_fwd_band total");
+	const int mask = band_mask(E);
+	std::vector<FwdProb> probs(n);
+	for (int k = 0; k < n; k++) { probs[k].tbase = (int64_t)W[k].unit * B.tstride + W[k].t0; probs[k].len = W[k].len; probs[k].stream_off = 0; }
+	int rc = upload_async(E, E->fprobs, probs.data(), sizeof(FwdProb) * n); if (rc) return rc;
+	HIPOK(E->fout.ensure(sizeof(FwdOut) * n));
+	HIPOK(E->bcounts.ensure(64));
+	for (int c = 0; c < 3; c++) {
+		if (!((mask >> c) & 1)) continue;
+		HIPOK(E->blist[c].ensure(sizeof(BandTry) * (size_t)n));
+		HIPOK(E->bslots[c].ensure(sizeof(uint16_t) * BAND_SLOT_COLS * (size_t)n));
+	}
+	static const bool second = [] { const char* e = getenv("FASIM_BAND_SECOND"); return e ? atoi(e) != 0 : true; }();
+	std::vector<int32_t> idx, tgt2;
+	for (int pass = 0; pass < (second ? 2 : 1); pass++) {
+		int np = n;
+		const int32_t* tsrc = target.data();
+		if (pass == 1) {
+			idx.clear(); tgt2.clear();
+			for (int k = 0; k < n; k++) if (fo[k].flags == 8 && fo[k].score > 0) { idx.push_back(k); tgt2.push_back(fo[k].score); }
+			np = (int)idx.size(); tsrc = tgt2.data();
+			if (!np) break;
+			rc = upload_async(E, E->bidx, idx.data(), sizeof(int32_t) * np); if (rc) return rc;
+		}
+		rc = upload_async(E, E->btarget, tsrc, sizeof(int32_t) * np); if (rc) return rc;
+		BandSelLaunch S;
+		S.probs = E->fprobs.as<FwdProb>(); S.target = E->btarget.as<int32_t>(); S.idx = pass ? E->bidx.as<int32_t>() : nullptr; S.n = np; S.tstride = B.tstride;
+		S.ublk = E->ub_view ? E->ub_view : E->ublk.as<uint32_t>(); S.ublk_blocks = E->ublk_blocks; S.m = E->m; S.tcodes = tcv(E);
+		for (int c = 0; c < 3; c++) { S.list[c] = E->blist[c].as<BandTry>(); S.slots[c] = E->bslots[c].as<uint16_t>(); }
+		S.list_cap = (uint32_t)n; S.counts = E->bcounts.as<uint32_t>(); S.out = E->fout.as<FwdOut>(); S.class_mask = mask;
+		hipError_t he;
+		{ TimedScope ts(E, 9); he = launch_band_select(S, E->st); }
+		if (he != hipSuccess) return fail(E, FASIM_E_HIP, "band_select launch failed: %s", hipGetErrorString(he));
+		uint32_t counts[8] = { 0 };
+		HIPOK(hipMemcpyAsync(counts, E->bcounts.p, sizeof counts, hipMemcpyDeviceToHost, E->st));
+		HIPOK(hipStreamSynchronize(E->st));       // (the host vectors uploaded above may go out of scope from here on)
+		if (counts[0] + counts[1] + counts[2]) {
+			GateScope gate(E);
+			for (int c = 0; c < 3; c++) {
+				if (!counts[c]) continue;
+				BandLaunch L;
+				L.list = E->blist[c].as<BandTry>(); L.slots = E->bslots[c].as<uint16_t>(); L.n = (int)counts[c]; L.cls = c;
+				L.qcodes = E->q2.as<uint8_t>(); L.m = E->m; L.out = E->fout.as<FwdOut>();
+				{ TimedScope ts(E, 8, E->st_heavy); he = launch_align_band(L, E->st_heavy); }
+				if (he != hipSuccess) return fail(E, FASIM_E_HIP, "align_band launch failed: %s", hipGetErrorString(he));
+				if (st) { st->band_tries += counts[c]; st->band_cells += (int64_t)counts[4 + c] * 48 * (8 << c); st->cells_stage3 += (int64_t)counts[4 + c] * 48 * (8 << c); }
+			}
+			HIPOK(hipStreamSynchronize(E->st_heavy));
+		}
+		HIPOK(hipMemcpyAsync(fo.data(), E->fout.p, sizeof(FwdOut) * n, hipMemcpyDeviceToHost, E->st));
+		HIPOK(hipStreamSynchronize(E->st));
+	}
+	if (st) for (int k = 0; k < n; k++) if (!(fo[k].flags & 24)) st->band_proven++;
+	return FASIM_OK;
+}
+
+// forward pass of a round of tries: banded where the block maxima of k_scan prove a band, full height otherwise
+int run_fwd_smart(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, const std::vector<int32_t>& target,
+	std::vector<FwdOut>& fo, fasim_scan_stats& st)
+{
+	const bool band = band_mask(E) != 0 && (E->ub_view || E->ublk_units >= B.nunit) && E->ublk_blocks > 0;
+	if (!band) {
+		for (const WindowProb& w : W) st.cells_stage3 += (int64_t)E->m * w.len;
+		return run_fwd_both(E, B, W, fo, &st.align_word_reruns);
+	}
+	int rc = run_fwd_band(E, B, W, target, fo, &st); if (rc) return rc;
+	std::vector<int> rest;
+	for (size_t k = 0; k < fo.size(); k++) if (fo[k].flags & 24) rest.push_back((int)k);
+	if (rest.empty()) return FASIM_OK;
+	std::vector<WindowProb> W3(rest.size()); std::vector<FwdOut> f3;
+	for (size_t r = 0; r < rest.size(); r++) { W3[r] = W[rest[r]]; st.cells_stage3 += (int64_t)E->m * W3[r].len; }
+	rc = run_fwd_both(E, B, W3, f3, &st.align_word_reruns); if (rc) return rc;
+	for (size_t r = 0; r < rest.size(); r++) fo[rest[r]] = f3[r];
+	return FASIM_OK;
+}
+
 // exact (stripe-faithful) reverse pass for windows whose forward result is exact but whose score (>= 148) would allow
 // the signed lazy-F exit in the reverse pass.  Fills fo[k].score = min(forward, reverse), ref_begin, read_begin, flag 2;
 // flag 1 is set where the result cannot be used (caller replays the candidate).
@@ -1176,7 +1286,8 @@ void fasim_engine_destroy(fasim_engine* e)
 		&e->ends, &e->bprobs, &e->bout, &e->scratch, &e->dna_res, &e->colmax16, &e->unit_ids, &e->flags, &e->stage1_in, &e->hits2,
 		&e->fprobs, &e->ftasks, &e->fstream, &e->fout, &e->aout, &e->cigpool, &e->cigcount, &e->forder, &e->scratch2, &e->boundary, &e->fboundary, &e->unit_hz,
 		&e->unit_first, &e->hz_cols, &e->hz_plan, &e->hz_base, &e->hz_items, &e->snap, &e->hz_state, &e->hz_rows, &e->hz_chunk, &e->hz_src, &e->hz_zero,
-		&e->qsim, &e->sim_min, &e->sim_row, &e->sim_ev, &e->sim_cnt, &e->sim_nodes };
+		&e->qsim, &e->sim_min, &e->sim_row, &e->sim_ev, &e->sim_cnt, &e->sim_nodes,
+		&e->ublk, &e->btarget, &e->bidx, &e->bcounts, &e->blist[0], &e->blist[1], &e->blist[2], &e->bslots[0], &e->bslots[1], &e->bslots[2] };
 	for (auto& t : e->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
 	for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
 	for (DevBuf* b : bufs) b->release();
@@ -1198,6 +1309,7 @@ int fasim_set_option(fasim_engine* E, const char* key, int32_t value)
 	else if (!strcmp(key, "hazard_chunk_cols")) E->hz_target = value > 0 ? std::max(64, value) : 0;
 	else if (!strcmp(key, "hazard_hot_weight")) E->hz_hot_w = value > 0 ? std::min(32, value) : 0;
 	else if (!strcmp(key, "host_threads")) { if (value > 0) { E->host_threads = value; E->host_threads_total = value; E->host_threads_explicit = true; } }   // host side of the batches (all workers together)
+	else if (!strcmp(key, "band")) E->opt_band = value;                   // banded stage-3 forward pass: 0 off, 1 on (-1: default / FASIM_BAND)
 	else if (!strcmp(key, "tail_split")) E->opt_tail_split = value > 0 ? value : 0;
 	else if (!strcmp(key, "tail_items")) E->opt_tail_items = value;
 	else return fail(E, FASIM_E_ARG, "unknown option %s", key);
@@ -1543,6 +1655,7 @@ struct BatchCtx {
 	std::vector<int32_t> hoff, hcnt, thr; std::vector<uint32_t> hits;
 	std::vector<char> seg_acgtn;
 	const uint8_t* tcodes_dev = nullptr;
+	const uint32_t* ublk_dev = nullptr; int ublk_blocks = 0;      // block maxima of the batch's k_scan pass (banded stage 3); NULL: none
 	const char* dna = nullptr; const fasim_params* p = nullptr; const std::vector<int>* encs = nullptr;
 	std::vector<std::vector<HostTriplex>> per_unit;     // [unit]: records of the unit after fastSIM's own filter
 	bool stage3_done = false;                           // -F: the whole batch was finished in the scan phase
@@ -1703,6 +1816,7 @@ int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t*
 		}
 		// the scan phase ends here: stage 3 runs per unit range (stage3_range), on this engine or on helpers
 		C.tcodes_dev = E->tcodes.as<uint8_t>();
+		C.ublk_dev = E->ublk_units >= B.nunit ? E->ublk.as<uint32_t>() : nullptr; C.ublk_blocks = E->ublk_blocks;
 		C.per_unit.assign((size_t)B.nunit, std::vector<HostTriplex>());
 		C.seg_acgtn.resize((size_t)nseg);
 		for (int s = 0; s < nseg; s++) C.seg_acgtn[(size_t)s] = only_acgtn(dna + sidx[(size_t)s] * step, slen[(size_t)s]) ? 1 : 0;
@@ -1723,7 +1837,11 @@ int stage3_range(fasim_engine* E, BatchCtx& C, int ua, int ub, fasim_scan_stats&
 	const int nenc = C.nenc;
 	const std::vector<int32_t>& slen = C.slen; const std::vector<int64_t>& sidx = C.sidx;
 	const std::vector<int32_t>& hoff = C.hoff; const std::vector<int32_t>& hcnt = C.hcnt; const std::vector<uint32_t>& hits = C.hits;
-	struct ViewScope { fasim_engine* e; ViewScope(fasim_engine* e_, const uint8_t* v) : e(e_) { e->tc_view = v; } ~ViewScope() { e->tc_view = nullptr; } } view(E, C.tcodes_dev);
+	struct ViewScope {
+		fasim_engine* e; int blocks;
+		ViewScope(fasim_engine* e_, const BatchCtx& c) : e(e_), blocks(e_->ublk_blocks) { e->tc_view = c.tcodes_dev; e->ub_view = c.ublk_dev; if (c.ublk_dev) e->ublk_blocks = c.ublk_blocks; }
+		~ViewScope() { e->tc_view = nullptr; e->ub_view = nullptr; e->ublk_blocks = blocks; }
+	} view(E, C);
 	double t0;
 	{
 
@@ -1775,9 +1893,16 @@ int stage3_range(fasim_engine* E, BatchCtx& C, int ua, int ub, fasim_scan_stats&
 				}
 				if (W.empty()) break;
 				st.align_calls += (int64_t)W.size();
-				for (const WindowProb& w : W) st.cells_stage3 += (int64_t)E->m * w.len;
+				// what the try is expected to score: the candidate's own score at the first try (an accepted try reaches it), a
+				// fraction of the previous try's score afterwards (the windows shrink)
+				static const int rho = [] { const char* e = getenv("FASIM_BAND_RHO"); const int v = e ? atoi(e) : 85; return v < 10 ? 10 : (v > 100 ? 100 : v); }();
+				std::vector<int32_t> target(W.size());
+				for (size_t i = 0; i < who.size(); i++) {
+					const CandState& x = cs[who[i]];
+					target[i] = it == 0 ? x.c.score : std::max(1, x.fsel.score * rho / 100);
+				}
 				std::vector<FwdOut> fo;
-				rc = run_fwd_both(E, B, W, fo, &st.align_word_reruns); if (rc) return rc;
+				rc = run_fwd_smart(E, B, W, target, fo, st); if (rc) return rc;
 				std::vector<int> fwd_score(fo.size());
 				for (size_t i = 0; i < fo.size(); i++) fwd_score[i] = fo[i].score;
 				{
@@ -2039,7 +2164,8 @@ static void add_stats(fasim_scan_stats& st, const fasim_scan_stats& x)
 	st.t_stage2_s += x.t_stage2_s; st.t_stage3_s += x.t_stage3_s; st.t_host_s += x.t_host_s; st.cells_stage1 += x.cells_stage1;
 	st.cells_stage2 += x.cells_stage2; st.cells_stage3 += x.cells_stage3; st.hazard_units += x.hazard_units; st.rev_exact += x.rev_exact;
 	st.exact_replays += x.exact_replays; st.tries_skipped += x.tries_skipped;
-	for (int k = 0; k < 8; k++) { st.kernel_ms[k] += x.kernel_ms[k]; st.kernel_launches[k] += x.kernel_launches[k]; }
+	st.band_tries += x.band_tries; st.band_proven += x.band_proven; st.band_cells += x.band_cells;
+	for (int k = 0; k < FASIM_KERNEL_FAMILIES; k++) { st.kernel_ms[k] += x.kernel_ms[k]; st.kernel_launches[k] += x.kernel_launches[k]; }
 }
 
 // The body of fasim_scan / fasim_scan_queries: every (query, batch of segments) pair is one work item; the worker engines
@@ -2178,7 +2304,7 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 		for (fasim_engine* w : ws) {
 			w->gate = (ws.size() > 1 && E->own_gate.cap > 0) ? &E->own_gate : nullptr;
 			w->scan_v1 = E->scan_v1; w->align_v1 = E->align_v1;
-			w->hz_chunks = E->hz_chunks; w->hz_snap = E->hz_snap; w->hz_target = E->hz_target; w->hz_hot_w = E->hz_hot_w;
+			w->hz_chunks = E->hz_chunks; w->hz_snap = E->hz_snap; w->hz_target = E->hz_target; w->hz_hot_w = E->hz_hot_w; w->opt_band = E->opt_band;
 			w->host_threads = std::max(1, E->host_threads_total / nworkers);
 			w->host_threads_share_total = E->host_threads_total; w->active_workers = &active_workers;
 			{
@@ -2189,7 +2315,7 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 			HIPOK(hipSetDevice(E->device));
 			int rc = upload(w, w->enc_ids, encs.data(), sizeof(int) * nenc); if (rc) return rc;
 			drain_timed(w);
-			for (int k = 0; k < 8; k++) { w->kernel_ms[k] = 0; w->kernel_launches[k] = 0; }
+			for (int k = 0; k < FASIM_KERNEL_FAMILIES; k++) { w->kernel_ms[k] = 0; w->kernel_launches[k] = 0; }
 		}
 		std::vector<std::vector<HostTriplex>> per_item(items.size());
 		std::vector<fasim_scan_stats> ist(items.size());
@@ -2220,7 +2346,7 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 			if (!r) r = stage3_range(w, R.ctx, t.ua, t.ub, local);
 			(void)hipStreamSynchronize(w->st);
 			drain_timed(w);
-			for (int k = 0; k < 8; k++) { local.kernel_ms[k] = w->kernel_ms[k]; local.kernel_launches[k] = w->kernel_launches[k]; w->kernel_ms[k] = 0; w->kernel_launches[k] = 0; }
+			for (int k = 0; k < FASIM_KERNEL_FAMILIES; k++) { local.kernel_ms[k] = w->kernel_ms[k]; local.kernel_launches[k] = w->kernel_launches[k]; w->kernel_ms[k] = 0; w->kernel_launches[k] = 0; }
 			{
 				std::lock_guard<std::mutex> lk(R.mu);
 				add_stats(R.st3, local);
@@ -2262,7 +2388,7 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 				if (!r) r = scan_batch(w, dna, dna_len, dna_dev, shard_lo, itx.b0, itx.b1, p, encs, tstride, R.ctx, ist[c]);
 				(void)hipStreamSynchronize(w->st);
 				drain_timed(w);
-				for (int k = 0; k < 8; k++) { ist[c].kernel_ms[k] = w->kernel_ms[k]; ist[c].kernel_launches[k] = w->kernel_launches[k]; w->kernel_ms[k] = 0; w->kernel_launches[k] = 0; }
+				for (int k = 0; k < FASIM_KERNEL_FAMILIES; k++) { ist[c].kernel_ms[k] = w->kernel_ms[k]; ist[c].kernel_launches[k] = w->kernel_launches[k]; w->kernel_ms[k] = 0; w->kernel_launches[k] = 0; }
 				const int nunit = R.ctx.B.nunit;
 				if (!r && nunit > 0 && !R.ctx.stage3_done) {
 					const bool in_tail = items.size() - c <= tail_items;

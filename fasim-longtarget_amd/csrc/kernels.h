@@ -70,7 +70,12 @@ struct ScanLaunch {
 	const ScanDumpItem* dump_items = nullptr;
 	const int32_t* dump_cols = nullptr;     // [chunk]: the column after which the DP state of all rows is wanted (ascending within an item)
 	uint16_t* dump_state = nullptr;         // [chunk][2][16 * ceil(m/16)]: H, then the reference's E
+	// block maxima for the banded stage 3 (band.hip): [unit][tile][ublk_blocks][64 lanes] dwords; NULL: not wanted
+	uint32_t* ublk = nullptr;
+	int32_t ublk_blocks = 0;
 };
+constexpr int SCAN_UBLK_STEPS = 64;       // pipeline steps per block of maxima
+inline int scan_ublk_blocks(int tstride) { return (tstride + 127 + SCAN_UBLK_STEPS - 1) / SCAN_UBLK_STEPS; }
 int systolic_vs(int m);
 int systolic_tiles(int m);     // query tiles of 128 virtual lanes x <= 24 rows (1 for m <= 3072)
 bool systolic_fits(int m);
@@ -97,6 +102,22 @@ hipError_t launch_finish(const uint8_t* tcodes, const uint8_t* qcodes, const Fwd
 hipError_t launch_finish_big(const uint8_t* tcodes, const uint8_t* qcodes, const FwdProb* probs, const FwdOut* fwd,
 	const int32_t* idx_list, int32_t nlist, uint8_t* scratch, int32_t scratch_cap, AlignOutDev* out, uint32_t* cigar_pool,
 	uint32_t pool_cap, uint32_t* pool_count, hipStream_t st);
+
+// ---- band.hip: banded forward pass of stage 3 -------------------------------------------------------------
+// one selected try: the band kernel sweeps rows [r0, r0 + 48 G) of window `prob`; its result is the reference's iff the
+// score reaches theta_min; nq = length of the try's column stream in groups of 4 columns
+struct BandTry { int32_t prob, r0, theta_min, nq; };
+constexpr int BAND_SLOT_COLS = 208;       // 16-bit stream words per try (window <= 200 columns + 2 void columns, rounded up to 4)
+struct BandSelLaunch {
+	const FwdProb* probs; const int32_t* target; const int32_t* idx; int32_t n, tstride;
+	const uint32_t* ublk; int32_t ublk_blocks; int32_t m; const uint8_t* tcodes;
+	BandTry* list[3]; uint16_t* slots[3]; uint32_t list_cap; uint32_t* counts; FwdOut* out; int32_t class_mask;
+};
+struct BandLaunch { const BandTry* list; const uint16_t* slots; int32_t n, cls; const uint8_t* qcodes; int32_t m; FwdOut* out; };
+int band_profile_lanes(int m);
+int band_classes(int m);              // bit c set: class c (sub-pipelines of 8 << c lanes = 384 << c rows) is available for this query
+hipError_t launch_band_select(const BandSelLaunch& L, hipStream_t st);
+hipError_t launch_align_band(const BandLaunch& L, hipStream_t st);
 
 // ---- sim.hip: forward sweep of classic SIM (-F), one wave per unit ---------------------------------------
 hipError_t launch_sim_forward(const SimFwdArgs& a, int32_t nunit, hipStream_t st);

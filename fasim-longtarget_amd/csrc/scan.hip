@@ -111,6 +111,11 @@ struct ScanArgs {
 	const int32_t* dump_cols;
 	uint16_t* dump_state;
 	int32_t rows_total;          // 16 * ceil(m/16)
+	// block maxima for the banded stage 3 (band.hip): per unit, query tile and block of SCAN_UBLK_STEPS pipeline steps one dword per
+	// lane = the maximum (as carried: 2 * value + taint) over the rows of the lane's two virtual lanes and the steps of the block;
+	// virtual lane v of the tile sees column c at step c + v.  [unit][tile][block][64 lanes]; NULL: not wanted
+	uint32_t* ublk;
+	int32_t ublk_blocks;         // blocks per (unit, tile) in the buffer
 };
 
 // rows owned by global virtual lane v (stripe-aligned layout): stripe s = v / vs gets its ceil(m/16) rows spread over
@@ -133,41 +138,16 @@ __device__ __forceinline__ int scan_cell_score(const ScanArgs& a, int t, int v, 
 	return 0;                                 // rows [m, 16*segLen) are the reference's zero-score pad rows (Q3)
 }
 
-// 24 rows x {lo, hi} int16 = 96 B per lane.  A ds_read_b128 serves 16 lanes per pass; with a plain 96-B (24-dword) lane
-// stride lanes l and l+8 start on the same bank (measured: SQ_LDS_BANK_CONFLICT = 4 cycles per read), so every group
-// of 8 lanes is skewed by 16 B more: lane offset = (lane >> 3) * 784 + (lane & 7) * 96, all 16 windows distinct.
-constexpr int PAIR_LANE_STRIDE = 96;
-constexpr int PAIR_GROUP_STRIDE = 8 * PAIR_LANE_STRIDE + 16;   // 784 B
-constexpr int PAIR_STRIDE = 6400;             // >= 8 * 784 B per (code of half lo, code of half hi); a multiple of the 256-B bank row,
-                                              // so that lanes holding different pairs keep their bank pattern
-constexpr int PAIR_LDS = 17 * PAIR_STRIDE;    // 108 800 B: 16 pairs over A,C,G,T plus (N, N); one 1024-thread workgroup per CU, which
-                                              // leaves 55 KB of the CU's LDS to the latency-bound kernels of the other batches
-__device__ __forceinline__ int pair_lane_offset(int lane) { return (lane >> 3) * PAIR_GROUP_STRIDE + (lane & 7) * PAIR_LANE_STRIDE; }
-
-// PAIR = false: 256-thread workgroups, per-code int16 profile (35 KB), the two halves of a lane fetch their own code's
-//               rows and a v_perm_b32 per row merges them;
-// PAIR = true : 1024-thread workgroups (16 waves = the whole CU), profile stored per PAIR of codes already merged
-//               (16 pairs of bases + the pair (N, N), 6.4 KB each): one VALU op per row less.  A lane whose halves are
-//               (base, N) -- the front of the pipeline while it fills or drains, or a real N in the DNA -- reads the
-//               pair with A in place of N and patches the N half in (a wave-uniform branch, ~2.5 % of the steps).
-template <int RP, bool PAIR, bool DUMP = false>
-__global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves_per_eu(DUMP ? 1 : 4, DUMP ? 2 : 4))) k_scan(ScanArgs a)
+// One 256-thread workgroup shares the per-code int16 profile (35 KB); the two halves of a lane fetch their own code's rows and a
+// v_perm_b32 per row merges them.  (A variant with the profile stored per PAIR of codes -- no perm, 109 KB of LDS, 1024-thread
+// workgroups -- was 5 % faster alone and 1-4 % slower with ten batches in flight; it was removed in round 3.)
+template <int RP, bool DUMP = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DUMP ? 1 : 4, DUMP ? 2 : 4))) k_scan(ScanArgs a)
 {
 	extern __shared__ __align__(16) uint8_t prof[];
 	const int lane = threadIdx.x & 63;
 
-	if constexpr (PAIR) {
-		// ---- prof[t_lo * 4 + t_hi][lane][r] = { score(t_lo, row r of virtual lane 2*lane), score(t_hi, ... 2*lane+1) };
-		//      pair 16 = (N, N)
-		for (int idx = threadIdx.x; idx < 17 * 64 * 24; idx += blockDim.x) {
-			const int r = idx % 24;
-			const int l = (idx / 24) % 64;
-			const int pr = idx / (24 * 64);
-			const int lo = scan_cell_score(a, pr == 16 ? 4 : pr / 4, 128 * a.tile + 2 * l, r);
-			const int hi = scan_cell_score(a, pr == 16 ? 4 : pr % 4, 128 * a.tile + 2 * l + 1, r);
-			*reinterpret_cast<uint32_t*>(prof + pr * PAIR_STRIDE + pair_lane_offset(l) + r * 4) = ((uint32_t)(uint16_t)(int16_t)lo) | ((uint32_t)(uint16_t)(int16_t)hi << 16);
-		}
-	} else {
+	{
 		// ---- stage the int16 profile: prof[t][lane][half][r] -------------------------------------------
 		// stripe-aligned layout: the reference's stripe s = rows [s*segLen, (s+1)*segLen) is spread over `vs` virtual
 		// lanes, so every stripe boundary is a virtual-lane boundary; this launch stages the rows of its tile only
@@ -186,13 +166,10 @@ __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves
 	//       its incoming F; Q2 needs F[b] >= 132 (doubled: > 263), other halves never flag.
 	// act : 0xFFFF where the half owns RP rows, 0 where it owns RP-1 (its last register row is transparent)
 	uint32_t fthr = 0xFFFFFFFFu, act = 0, startbits = 0;
-	uint32_t realc = 0, rowsc = 0;               // per half: rows with a real query letter / rows owned (N patch of PAIR)
 	for (int h = 0; h < 2; h++) {
 		const int v = 128 * a.tile + 2 * lane + h;        // global virtual lane
 		int row0, rows_v;
 		lane_rows(v, a.seg_len16, a.vs, &row0, &rows_v);
-		const int real = a.m - row0 < 0 ? 0 : (a.m - row0 > rows_v ? rows_v : a.m - row0);
-		realc |= (uint32_t)real << (16 * h); rowsc |= (uint32_t)rows_v << (16 * h);
 		if (v % a.vs == 0 && v > 0) { fthr = (fthr & ~(0xFFFFu << (16 * h))) | (263u << (16 * h)); startbits |= 0xFFFFu << (16 * h); }
 		if (rows_v == RP) act |= 0xFFFFu << (16 * h);
 	}
@@ -202,8 +179,7 @@ __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves
 	const v2u startm = __builtin_bit_cast(v2u, startbits);
 	// the refined test needs F to die inside one stripe (F <= 234 decays by 4 per row)
 	const bool lvl2 = a.seg_len16 >= 96 && !a.coarse;
-	const int pl_off = PAIR ? pair_lane_offset(lane) : lane * SCAN_LANE_STRIDE;
-	const uint8_t* pl = prof + pl_off;
+	const uint8_t* pl = prof + lane * SCAN_LANE_STRIDE;
 
 	for (;;) {
 		int w = 0;
@@ -230,6 +206,7 @@ __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves
 		v2u hzacc = (v2u){ 0, 0 };      // != 0: the unit goes to the stripe-faithful kernel (coarse test of short queries)
 		int chunk = CODE_N;
 		int first_enter = 0x7fffffff;          // first step of this unit in which the hazard branch ran (wave-uniform)
+		v2u ubacc = (v2u){ 0, 0 };             // running maximum of the current block of steps (banded stage 3)
 		// DUMP only: the reference's OWN E.  Its lazy-F loop corrects H but not E (sswNew.cpp:355: "don't update E"), so E follows
 		// the H of the main pass, which only knows the F chain restarted at the top of each stripe (Fm).  The H values are the
 		// same either way (a gap pair in the order down-right scores what right-down scores), the E array is not, and a
@@ -282,54 +259,25 @@ __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves
 				recv_cm = vshift(cm, (int)(by << 16)); recv_fp = vshift(fpo, (int)(by & 0xffff0000u));
 			}
 			const int t_lo = tc & 0xff, t_hi = (tc >> 16) & 0xff;
-			// PAIR: byte offset of the pair's rows = min(t_lo, 3) * 4 * PAIR_STRIDE + min(t_hi, 3) * PAIR_STRIDE + lane offset (one
-			// v_dot2_u32_u16), or pair 16 when both halves hold N
-			const v2u tcv = __builtin_bit_cast(v2u, tc);
-			const v2u isn = __builtin_elementwise_sub_sat(tcv, (v2u){ 3, 3 });            // 1 where the half holds N (code 4)
-			const uint8_t* pa;
-			if constexpr (PAIR) {
-				const unsigned off = __builtin_amdgcn_udot2(__builtin_elementwise_min(tcv, (v2u){ 3, 3 }), (v2u){ 4 * PAIR_STRIDE, PAIR_STRIDE }, (unsigned)pl_off, false);
-				pa = prof + (to_int(isn) == 0x00010001 ? (unsigned)(16 * PAIR_STRIDE + pl_off) : off);
-			} else pa = pl + t_lo * SCAN_CODE_STRIDE;
-			const uint8_t* pb = pl + t_hi * SCAN_CODE_STRIDE + 48;      // (!PAIR only)
+			const uint8_t* pa = pl + t_lo * SCAN_CODE_STRIDE;
+			const uint8_t* pb = pl + t_hi * SCAN_CODE_STRIDE + 48;
 			const int hdiag0 = recv_h_last;           // H[i0-1][c-1]
 			recv_h_last = recv_h;
 			v2u f = __builtin_bit_cast(v2u, recv_f);
 			v2u fm = (v2u){ 0, 0 };
 			if constexpr (DUMP) fm = __builtin_bit_cast(v2u, vshift0(fmbot)) & ~startm;      // the main pass starts every stripe with F = 0
 			v2s lmx[4] = { (v2s){ 0, 0 }, (v2s){ 0, 0 }, (v2s){ 0, 0 }, (v2s){ 0, 0 } };   // independent chains: no back-to-back dependent v_pk_max
-			constexpr int ROWS_PER_LOAD = PAIR ? 4 : 8;
+			constexpr int ROWS_PER_LOAD = 8;
 			constexpr int NLOAD = (RP + ROWS_PER_LOAD - 1) / ROWS_PER_LOAD;
 			v4i PA[NLOAD], PB[NLOAD];
 #pragma unroll
 			for (int g = 0; g < NLOAD; g++) {
 				PA[g] = *reinterpret_cast<const v4i*>(pa + 16 * g);
-				if constexpr (!PAIR) PB[g] = *reinterpret_cast<const v4i*>(pb + 16 * g); else PB[g] = PA[g];
-			}
-			if constexpr (PAIR) {
-				// exactly one half on N: that half was read from the rows of A; N scores -4 (doubled: -8) against every real row,
-				// 0 against the pad rows, and the rows beyond the half's share stay dead
-				const v2u mixed = isn ^ (v2u){ (unsigned short)(to_int(isn) >> 16), (unsigned short)to_int(isn) };   // isn.lo != isn.hi, both halves
-				if (__builtin_amdgcn_ballot_w64(to_int(mixed) != 0) != 0ull) {
-					const v2u nmask = ((v2u){ 0, 0 } - isn) & ((v2u){ 0, 0 } - mixed);
-					// an N column scores the same against every real query row (-4 in stage 2, -1 in the stage-1 alphabet), doubled
-					const unsigned short nv = (unsigned short)(2 * a.score[4 * 5 + 0]);
-					const v2u nval = (v2u){ nv, nv };
-#pragma unroll
-					for (int r = 0; r < RP; r++) {
-						const v2u rr = (v2u){ (unsigned short)r, (unsigned short)r };
-						const v2u isreal = __builtin_elementwise_min(__builtin_elementwise_sub_sat(u_fromi((int)realc), rr), (v2u){ 1, 1 });
-						const v2u islive = __builtin_elementwise_min(__builtin_elementwise_sub_sat(u_fromi((int)rowsc), rr), (v2u){ 1, 1 });
-						const v2u nsc = (isreal * nval) | ((islive - (v2u){ 1, 1 }) & (v2u){ (unsigned short)SCAN_DEAD, (unsigned short)SCAN_DEAD });
-						const int g = r >> 2, k = r & 3;
-						PA[g][k] = (int)(((uint32_t)PA[g][k] & ~(uint32_t)to_int(nmask)) | ((uint32_t)to_int(nsc) & (uint32_t)to_int(nmask)));
-					}
-				}
+				PB[g] = *reinterpret_cast<const v4i*>(pb + 16 * g);
 			}
 			auto score_of = [&](int r) -> int {
 				const int g = r / ROWS_PER_LOAD, k = r % ROWS_PER_LOAD;
-				if constexpr (PAIR) return PA[g][k];
-				else return __builtin_amdgcn_perm(PB[g][k >> 1], PA[g][k >> 1], (k & 1) ? 0x07060302 : 0x05040100);
+				return __builtin_amdgcn_perm(PB[g][k >> 1], PA[g][k >> 1], (k & 1) ? 0x07060302 : 0x05040100);
 			};
 			// Row r needs the OLD H[r-1] (diagonal) and writes the NEW H[r].  The add of row r+1 (old H[r] + its score) is
 			// issued before H[r] is overwritten, so the new value can go into the same register: no second copy of the H
@@ -374,6 +322,7 @@ __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves
 			// pin the reduction here: if the compiler sinks it below the hazard branch, the 22 pre-branch H values stay alive
 			// next to the (possibly tainted) ones and the common path pays a register copy per row at the join
 			asm volatile("" :: "v"(to_int(lmax)));
+			if constexpr (!DUMP) ubacc = __builtin_elementwise_max(ubacc, as_u(lmax));
 			fbot = to_int(f);
 			if constexpr (DUMP) fmbot = to_int(fm);
 			// ---- Q2 hazard.  The reference's lazy-F loop leaves early (signed compare, sswNew.cpp:369) only while a
@@ -469,7 +418,7 @@ __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves
 		};
 		int step = DUMP ? item.step0 : 0;
 		for (; step + 1 < nsteps; step += 2) {
-			if constexpr (!DUMP && !PAIR) {
+			if constexpr (!DUMP) {
 				// pipeline snapshot (every SCAN_SNAP_STEPS steps, all lanes at once: ~50 stores per 1024 steps of ~230 instructions)
 				if (a.snap && step != 0 && (step & (SCAN_SNAP_STEPS - 1)) == 0 && step / SCAN_SNAP_STEPS <= a.snap_per_unit) {
 					uint32_t* sp = a.snap + ((size_t)unit * a.snap_per_unit + (step / SCAN_SNAP_STEPS - 1)) * (SNAP_DW * 64) + lane;
@@ -480,8 +429,19 @@ __global__ void __launch_bounds__(PAIR ? 1024 : 256) __attribute__((amdgpu_waves
 				}
 			}
 			do_step(step); do_step(step + 1);
+			if constexpr (!DUMP) {
+				// (steps come in pairs: a block of SCAN_UBLK_STEPS steps ends after an odd step)
+				if (((step + 1) & (SCAN_UBLK_STEPS - 1)) == SCAN_UBLK_STEPS - 1) {
+					if (a.ublk) a.ublk[(((size_t)unit * a.ntiles + a.tile) * a.ublk_blocks + (step / SCAN_UBLK_STEPS)) * 64 + lane] = (uint32_t)to_int(ubacc);
+					ubacc = (v2u){ 0, 0 };
+				}
+			}
 		}
 		if (step < nsteps) do_step(step);
+		if constexpr (!DUMP) {
+			// the last, partial block (nsteps - 1 is its last step unless the block was just closed)
+			if (a.ublk && (nsteps & (SCAN_UBLK_STEPS - 1)) != 0) a.ublk[(((size_t)unit * a.ntiles + a.tile) * a.ublk_blocks + ((nsteps - 1) / SCAN_UBLK_STEPS)) * 64 + lane] = (uint32_t)to_int(ubacc);
+		}
 		if (a.unit_hz && __builtin_amdgcn_ballot_w64(to_int(hzacc) != 0) != 0ull && lane == 0) atomicOr(a.unit_hz + unit, 1);
 		if (!DUMP && a.unit_first && first_enter != 0x7fffffff && lane == 0) atomicMin(a.unit_first + unit, first_enter);
 	}
@@ -492,38 +452,22 @@ static hipError_t launch_scan_dump_t(const ScanArgs& a, hipStream_t st)
 {
 	hipError_t err = hipMemsetAsync(a.counter, 0, sizeof(uint32_t), st);
 	if (err != hipSuccess) return err;
-	const long blocks = ((long)a.nwork + 3) / 4;              // one unit per wave
-	// FASIM_HAZARD_SPREAD=1 pads the LDS request past half a CU's 160 KB, so that a CU takes ONE workgroup and each of its four
-	// waves a SIMD of its own (for measurements: it made no difference on an idle chip, and beside four workgroups of the main
-	// pass, 140 KB of LDS, such a request cannot start at all).
-	static const bool spread = [] { const char* e = getenv("FASIM_HAZARD_SPREAD"); return e ? atoi(e) != 0 : false; }();
-	const int lds = spread ? 84 * 1024 : 5 * SCAN_CODE_STRIDE;
-	static bool attr_set = false;                   // (benign race: the call is idempotent)
-	if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_scan<RP, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024); attr_set = true; }
-	hipLaunchKernelGGL((k_scan<RP, false, true>), dim3((unsigned)blocks), dim3(256), (size_t)lds, st, a);
+	const long blocks = ((long)a.nwork + 3) / 4;              // one work item per wave
+	hipLaunchKernelGGL((k_scan<RP, true>), dim3((unsigned)blocks), dim3(256), (size_t)5 * SCAN_CODE_STRIDE, st, a);
 	return hipGetLastError();
 }
 
-template <int RP, bool PAIR>
+template <int RP>
 static hipError_t launch_scan_t(const ScanArgs& a, hipStream_t st)
 {
 	hipError_t err = hipMemsetAsync(a.counter, 0, sizeof(uint32_t), st);
 	if (err != hipSuccess) return err;
-	// Short-lived workgroups (each wave takes about `per_wave` units from the queue) instead of a persistent grid: slots
-	// free up every few milliseconds, so the latency-bound kernels of the other batches in flight get dispatched at once
-	// instead of waiting for this kernel to drain.  FASIM_GRID_UNITS=0 restores the persistent grid.
-	static const int per_wave = [] { const char* e = getenv("FASIM_GRID_UNITS"); return e ? atoi(e) : 2; }();
-	constexpr int WPB = PAIR ? 16 : 4;                   // waves per workgroup
-	const long waves = a.nwork;
-	long blocks = (waves + WPB - 1) / WPB;
-	if (per_wave > 0) blocks = (waves + WPB * per_wave - 1) / (WPB * per_wave);
-	else if (blocks > 256 * 16 / WPB) blocks = 256 * 16 / WPB;
-	const size_t lds = PAIR ? (size_t)PAIR_LDS : (size_t)5 * SCAN_CODE_STRIDE;
-	if (PAIR) {
-		static bool attr_set = false;                   // (benign race: the call is idempotent)
-		if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_scan<RP, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-	}
-	hipLaunchKernelGGL((k_scan<RP, PAIR>), dim3((unsigned)blocks), dim3(PAIR ? 1024 : 256), lds, st, a);
+	// Short-lived workgroups (each wave takes about two units from the queue) instead of a persistent grid: slots free up every
+	// few milliseconds, so the latency-bound kernels of the other batches in flight get dispatched at once instead of waiting
+	// for this kernel to drain.
+	constexpr int WPB = 4, PER_WAVE = 2;                 // waves per workgroup, units per wave
+	const long blocks = ((long)a.nwork + WPB * PER_WAVE - 1) / (WPB * PER_WAVE);
+	hipLaunchKernelGGL((k_scan<RP>), dim3((unsigned)blocks), dim3(256), (size_t)5 * SCAN_CODE_STRIDE, st, a);
 	return hipGetLastError();
 }
 
@@ -545,16 +489,16 @@ hipError_t launch_scan(const ScanLaunch& L, hipStream_t st)
 	a.colmax16 = L.colmax16; a.unit_hz = L.unit_hz; a.coarse = L.coarse;
 	a.vs = systolic_vs(L.m); a.ntiles = a.vs / 8; a.boundary = L.boundary;
 	a.unit_first = L.unit_first; a.snap = L.snap; a.snap_per_unit = L.snap_per_unit; a.dump_items = L.dump_items; a.dump_cols = L.dump_cols; a.dump_state = L.dump_state; a.rows_total = 16 * a.seg_len16;
+	a.ublk = L.dump_items ? nullptr : L.ublk; a.ublk_blocks = L.ublk_blocks;
 	if (a.ntiles > 1 && !a.boundary) return hipErrorInvalidValue;
 	// RP must be exactly ceil(segLen/vs): every virtual lane then owns RP or RP-1 rows.  One launch per tile of 128
 	// virtual lanes (long queries): tile t reads the bottom row tile t-1 left in `boundary` and overwrites it in place.
 	const int rp = (a.seg_len16 + a.vs - 1) / a.vs;
-	static const bool pair = [] { const char* e = getenv("FASIM_SCAN_PAIR"); return e ? atoi(e) != 0 : false; }();   // off: see DESIGN.md
 	for (int t = 0; t < a.ntiles; t++) {
 		a.tile = t;
 		hipError_t err = hipErrorInvalidValue;
 		switch (rp) {
-#define FASIM_SCAN_CASE(N) case N: err = L.dump_items ? launch_scan_dump_t<N>(a, st) : (pair ? launch_scan_t<N, true>(a, st) : launch_scan_t<N, false>(a, st)); break;
+#define FASIM_SCAN_CASE(N) case N: err = L.dump_items ? launch_scan_dump_t<N>(a, st) : launch_scan_t<N>(a, st); break;
 		FASIM_SCAN_CASE(1) FASIM_SCAN_CASE(2) FASIM_SCAN_CASE(3) FASIM_SCAN_CASE(4) FASIM_SCAN_CASE(5) FASIM_SCAN_CASE(6)
 		FASIM_SCAN_CASE(7) FASIM_SCAN_CASE(8) FASIM_SCAN_CASE(9) FASIM_SCAN_CASE(10) FASIM_SCAN_CASE(11) FASIM_SCAN_CASE(12)
 		FASIM_SCAN_CASE(13) FASIM_SCAN_CASE(14) FASIM_SCAN_CASE(15) FASIM_SCAN_CASE(16) FASIM_SCAN_CASE(17) FASIM_SCAN_CASE(18)

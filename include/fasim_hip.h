@@ -148,6 +148,7 @@ typedef struct fasim_triplex {
 	int64_t tfo_off, tts_off;           /* offsets of stri_align / strj_align in pool                */
 } fasim_triplex;
 
+#define FASIM_KERNEL_FAMILIES 10
 typedef struct fasim_scan_stats {
 	int64_t segments, segments_skipped, units;
 	int64_t candidates, align_calls;
@@ -159,13 +160,16 @@ typedef struct fasim_scan_stats {
 	 * batches in flight the durations include sharing the GPU).  index: 0 k_scan (fused stage 1+2), 1 k_striped
 	 * stage-1/2 (hazard re-runs, long queries), 2 k_align_fwd, 3 k_finish_lds, 4 encode/hits/post/stream,
 	 * 5 k_striped stage 3 (exact replays, exact reverse passes), 6 k_finish (global scratch) + k_banded, 7 k_sim_forward (-F) */
-	double  kernel_ms[8];
-	int64_t kernel_launches[8];
+	double  kernel_ms[FASIM_KERNEL_FAMILIES];      /* ... 8 k_align_band (banded stage-3 forward), 9 k_band_select */
+	int64_t kernel_launches[FASIM_KERNEL_FAMILIES];
 	int64_t cells_stage1, cells_stage2, cells_stage3;   /* DP cells actually executed (stage 3: fwd + rev)   */
 	int64_t hazard_units;               /* units re-run by the stripe-faithful kernel (possible Q2)  */
 	int64_t rev_exact;                  /* window tries whose reverse pass ran on the stripe-faithful kernel */
 	int64_t exact_replays;              /* candidates replayed try by try on the stripe-faithful kernels */
 	int64_t tries_skipped;              /* window tries of the reference whose result cannot matter and that were not run */
+	int64_t band_tries;                 /* forward passes run on a row band (k_align_band), second attempts included */
+	int64_t band_proven;                /* window tries whose band result was proven to be the full-height result */
+	int64_t band_cells;                 /* DP cells executed by k_align_band (part of cells_stage3) */
 } fasim_scan_stats;
 
 struct fasim_result {
