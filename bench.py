@@ -58,15 +58,13 @@ VALU_PK16_NOMINAL_TOPS = 256 * 4 * 64 / 4 * 2.4e9 / 1e12
 VALU_PLAIN_PEAK_TOPS = 256 * 4 * 64 / 2 * 2.4e9 / 1e12
 KERNEL_NAMES = ["k_scan (fused stage 1+2)", "k_striped<PRE|MAX1> (stage 1/2 hazard re-runs)", "k_align_fwd (stage 3 forward)",
                 "k_finish_lds (reverse pass + traceback)", "k_encode/k_scan_post/k_hits/k_build_stream",
-                "k_striped<ALIGN|REV> (stage 3 exact replays)", "k_finish/k_banded (global scratch)", "k_sim_forward (-F only)"]
+                "k_striped<ALIGN|REV> (stage 3 exact replays)", "k_finish/k_banded (global scratch)", "k_sim_forward (-F only)",
+                "k_align_band (stage 3 forward on row bands)", "k_band_select"]
+KERNEL_SHOWN = [0, 1, 2, 8, 9, 3, 4, 5, 6]
 # packed VALU instructions per DP cell of the variants that are launched by default:
-#   k_scan<RP,PAIR=false>: perm, add, 3 x max, 3 x sat-sub, 2 x max = 10 per row pair = 5.0 per cell
-#   k_align_fwd<RP,TAINT,PAIR=false>: the same + the row-key OR = 11 per row pair = 5.5 per cell
-def _env_on(name):
-    return os.environ.get(name, "0").strip() not in ("", "0")
-
-
-OPS_PER_CELL = {"k_scan": 4.5 if _env_on("FASIM_SCAN_PAIR") else 5.0, "k_align_fwd": 5.0 if _env_on("FASIM_FWD_PAIR") else 5.5}
+#   k_scan<RP>: perm, add, 3 x max, 3 x sat-sub, 2 x max = 10 per row pair = 5.0 per cell
+#   k_align_fwd<RP,TAINT> and k_align_band<G>: the same + the row-key OR = 11 per row pair = 5.5 per cell
+OPS_PER_CELL = {"k_scan": 5.0, "k_align_fwd": 5.5}
 
 
 def host_cores_uncapped():
@@ -358,10 +356,11 @@ def main():
             "executed_gcells_per_s": round(executed / tmax / 1e9, 3),
             "executed_cells_per_step": {k: int(agg[k] / args.steps) for k in ("cells_stage1", "cells_stage2", "cells_stage3")},
             "phase_wall_s_summed_over_batches": {k: round(agg[k], 3) for k in ("t_stage1_s", "t_stage2_s", "t_stage3_s", "t_host_s")},
-            "kernel_ms_overlapped": {KERNEL_NAMES[i]: round(kms[i], 2) for i in range(7)},
-            "kernel_launches": {KERNEL_NAMES[i]: int(agg["kernel_launches"][i]) for i in range(7)},
+            "kernel_ms_overlapped": {KERNEL_NAMES[i]: round(kms[i], 2) for i in KERNEL_SHOWN},
+            "kernel_launches": {KERNEL_NAMES[i]: int(agg["kernel_launches"][i]) for i in KERNEL_SHOWN},
             "counts": {k: int(agg[k]) for k in ("segments", "segments_skipped", "units", "candidates", "align_calls", "hazard_units", "rev_exact",
-                                                "exact_replays", "tries_skipped", "align_word_reruns", "stage2_overflow_units", "stage1_word_reruns")},
+                                                "exact_replays", "tries_skipped", "align_word_reruns", "stage2_overflow_units", "stage1_word_reruns",
+                                                "band_tries", "band_proven", "band_cells")},
             "per_unit": {"candidates": round(agg["candidates"] / max(1, agg["units"]), 2),
                          "hazard_units_pct": round(100.0 * agg["hazard_units"] / max(1, agg["units"]), 3),
                          "overflow_units_pct": round(100.0 * agg["stage2_overflow_units"] / max(1, agg["units"]), 3)},
@@ -377,7 +376,8 @@ def main():
         out["isolated_kernels"] = {
             "what": f"untimed pass over {iso['segments']} segments with ONE batch in flight (kernels run alone)",
             "units": iso["units"], "align_calls": iso["align_calls"], "hazard_units": iso["hazard_units"], "rev_exact": iso["rev_exact"],
-            "ms": {KERNEL_NAMES[i]: round(ik[i], 2) for i in range(7)},
+            "ms": {KERNEL_NAMES[i]: round(ik[i], 2) for i in KERNEL_SHOWN},
+            "band_tries": iso["band_tries"], "band_proven": iso["band_proven"], "band_cells": iso["band_cells"], "cells_stage3": iso["cells_stage3"],
             "dominant_kernel_ms_per_step_equivalent": round(ik[0] * units_per_step / max(1, iso["units"]), 1),
             # plan + checkpoint pass + all chunks of the stripe-faithful re-run (kernel family 1), scaled to one batch of 1024 segments
             "hazard_reruns_ms_per_49152_units": round(ik[1] * 49152 / max(1, iso["units"]), 2),

@@ -40,7 +40,8 @@ constexpr int BAND_RPB = 24;                 // rows per virtual lane (uniform; 
 constexpr int BAND_LANE_STRIDE = 112;        // bytes per lane in the LDS profile: 2 x 24 x int16 + 16 (bank-conflict-free b128)
 constexpr int BAND_SC = 32;                  // value scale: the low 5 bits of every H carry (31 - row in lane)
 constexpr int BAND_NEG = -32768;
-constexpr int BAND_FIFO = 8;                 // windows in flight per sub-pipeline (<= 2 G / 24 + 2)
+// windows in flight per sub-pipeline: a window is at least 4 stream columns and the pipe is 2 G columns deep -> at most G / 2 + 2;
+// the descriptor FIFO of a sub-pipeline holds G entries
 constexpr int BAND_VOID_BIT = 0x4000, BAND_LAST_BIT = 0x8000;
 constexpr int BAND_THREADS = 512;
 
@@ -68,101 +69,146 @@ struct BandSelArgs {
 };
 
 constexpr int SEL_MAXV = 2048;           // 16 tiles x 128 virtual lanes
+constexpr int SEL_TRIES = 64;            // tries per workgroup (16 per wave): ONE slot allocation per class and workgroup
 
+// Dynamic LDS: per wave ub[nv] and row0[nv + 1] (u16), then the decisions of the workgroup's tries.
 __global__ void __launch_bounds__(256) k_band_select(BandSelArgs a)
 {
-	__shared__ uint16_t s_ub[4][SEL_MAXV];
-	__shared__ uint16_t s_row0[4][SEL_MAXV + 1];
+	extern __shared__ __align__(16) uint16_t sel_lds[];
+	__shared__ int d_cls[SEL_TRIES], d_q0[SEL_TRIES], d_theta[SEL_TRIES], d_slot[SEL_TRIES];
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	const int w = blockIdx.x * 4 + wv;
-	if (w >= a.n) return;
-	const int p = a.idx ? a.idx[w] : w;
-	const FwdProb pb = a.probs[p];
-	const int L = pb.len;
-	const int unit = (int)(pb.tbase / a.tstride), t0 = (int)(pb.tbase - (int64_t)unit * a.tstride), pe = t0 + L - 1;
 	const int nv = 128 * a.ntiles;
-	uint16_t* ub = s_ub[wv]; uint16_t* r0s = s_row0[wv];
-	// ---- upper bounds per virtual lane of k_scan
-	int umax = 0;
-	for (int i = 0; i < a.ntiles; i++) {
-		const uint32_t* U = a.ublk + (((size_t)unit * a.ntiles + i) * a.ublk_blocks) * 64 + lane;
-		for (int h = 0; h < 2; h++) {
-			const int lv = 2 * lane + h, v = 128 * i + lv;
-			int u = 0;
-			for (int b = (t0 + lv) / SCAN_UBLK_STEPS; b <= (pe + lv) / SCAN_UBLK_STEPS; b++) {
-				const uint32_t x = U[(size_t)b * 64];
-				const int val = (int)((h ? (x >> 16) : (x & 0xffffu)) >> 1);      // 2 * value + taint
-				u = val > u ? val : u;
-			}
-			if (u > 5 * L) u = 5 * L;
-			ub[v] = (uint16_t)(u > 65535 ? 65535 : u);
-			int row0, rows; scan_lane_rows(v, a.seg16, a.vs, &row0, &rows);
-			r0s[v] = (uint16_t)row0;
-			umax = u > umax ? u : umax;
-		}
-	}
+	uint16_t* ub = sel_lds + (size_t)wv * (2 * nv + 2);
+	uint16_t* r0s = ub + nv;
+	// rows of k_scan's virtual lanes (the same for every try)
+	for (int v = lane; v < nv; v += 64) { int row0, rows; scan_lane_rows(v, a.seg16, a.vs, &row0, &rows); r0s[v] = (uint16_t)row0; }
 	if (lane == 0) r0s[nv] = (uint16_t)(16 * a.seg16);
-	for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(umax, o, 64); umax = x > umax ? x : umax; }
-	__builtin_amdgcn_wave_barrier();
-	int chosen = -1, ch_q0 = 0, ch_theta = 0;
-	int T = a.target[w];
-	if (T > umax) T = umax;
-	// a bound of 148 or more: the reference's signed lazy-F exit (Q2) or its 8-bit overflow could show -> full-height kernel
-	if (umax < 148 && T >= 1) {
-		int vf = 1 << 30, vl = -1;
-		for (int v = lane; v < nv; v += 64) if ((int)ub[v] >= T) { vf = v < vf ? v : vf; vl = v > vl ? v : vl; }
-		for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(vf, o, 64), y = __shfl_xor(vl, o, 64); vf = x < vf ? x : vf; vl = y > vl ? y : vl; }
-		// rows a path of score >= T can span inside L columns
-		const int gaps = 5 * L - T - 12;
-		const int rmax = gaps >= 4 ? L + gaps / 4 : L;
-		int top = (int)r0s[vf] - (rmax - 1); if (top < 0) top = 0;
-		const int bot = (int)r0s[vl + 1];
-		for (int c = 0; c < 3 && chosen < 0; c++) {
-			const int G = 8 << c;
-			if (!((a.class_mask >> c) & 1) || G > a.nl) continue;
-			int q0 = top / 48; if (q0 > a.nl - G) q0 = a.nl - G;
-			const int r0 = 48 * q0, r1 = r0 + 48 * G;
-			if (r1 < bot && q0 < a.nl - G) continue;                 // does not reach the last lane that matters
-			int theta = 1;
-			for (int v = lane; v < nv; v += 64) {
-				const int lo = r0s[v], hi = r0s[v + 1], u = ub[v];
-				int tau;
-				if (lo < r0 || hi > r1) tau = u + 1;                 // not entirely inside: must not reach theta
-				else if (r0 == 0) tau = 1;
-				else {
-					const int D = lo - r0 + 1;                         // rows available to a path that ends in this lane
-					const int ts = D >= L ? 9 * L - 4 * D - 15 : 5 * L + 1;
-					tau = u + 1 < ts ? u + 1 : ts;
-				}
-				theta = tau > theta ? tau : theta;
+	const int w0 = blockIdx.x * SEL_TRIES;
+	for (int k = 0; k < SEL_TRIES / 4; k++) {
+		const int slot_k = wv * (SEL_TRIES / 4) + k, w = w0 + slot_k;
+		if (w >= a.n) { if (lane == 0) d_cls[slot_k] = -2; continue; }
+		const int p = a.idx ? a.idx[w] : w;
+		const FwdProb pb = a.probs[p];
+		const int L = pb.len, unit = pb.stream_off;              // (the host passes the unit in the field the band path does not use)
+		const int t0 = (int)(pb.tbase - (int64_t)unit * a.tstride), pe = t0 + L - 1;
+		__builtin_amdgcn_wave_barrier();
+		// ---- upper bounds per virtual lane of k_scan: the blocks of steps [t0 + v, pe + v] (v = lane index inside the tile)
+		int umax = 0;
+		for (int i = 0; i < a.ntiles; i++) {
+			const uint32_t* U = a.ublk + (((size_t)unit * a.ntiles + i) * a.ublk_blocks) * 64 + lane;
+			const int b0 = (t0 + 2 * lane) / SCAN_UBLK_STEPS;
+			uint32_t x[5];
+#pragma unroll
+			for (int j = 0; j < 5; j++) { const int b = b0 + j < a.ublk_blocks ? b0 + j : a.ublk_blocks - 1; x[j] = U[(size_t)b * 64]; }
+			int u0 = 0, u1 = 0;
+			const int e0 = (pe + 2 * lane) / SCAN_UBLK_STEPS, s1 = (t0 + 2 * lane + 1) / SCAN_UBLK_STEPS, e1 = (pe + 2 * lane + 1) / SCAN_UBLK_STEPS;
+#pragma unroll
+			for (int j = 0; j < 5; j++) {
+				const int b = b0 + j;
+				const int lo = (int)((x[j] & 0xffffu) >> 1), hi = (int)(x[j] >> 17);         // 2 * value + taint per half
+				if (b <= e0) u0 = lo > u0 ? lo : u0;
+				if (b >= s1 && b <= e1) u1 = hi > u1 ? hi : u1;
 			}
-			for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(theta, o, 64); theta = x > theta ? x : theta; }
-			if (theta <= T) { chosen = c; ch_q0 = q0; ch_theta = theta; }
+			if (u0 > 5 * L) u0 = 5 * L;
+			if (u1 > 5 * L) u1 = 5 * L;
+			ub[128 * i + 2 * lane] = (uint16_t)u0; ub[128 * i + 2 * lane + 1] = (uint16_t)u1;
+			umax = u0 > umax ? u0 : umax; umax = u1 > umax ? u1 : umax;
 		}
+		for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(umax, o, 64); umax = y > umax ? y : umax; }
+		__builtin_amdgcn_wave_barrier();
+		int chosen = -1, ch_q0 = 0, ch_theta = 0;
+		int T = a.target[w];
+		if (T > umax) T = umax;
+		// a bound of 148 or more: the reference's signed lazy-F exit (Q2) or its 8-bit overflow could show -> full-height kernel
+		if (umax < 148 && T >= 1) {
+			int vf = 1 << 30, vl = -1;
+			for (int v = lane; v < nv; v += 64) if ((int)ub[v] >= T) { vf = v < vf ? v : vf; vl = v > vl ? v : vl; }
+			for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(vf, o, 64), z = __shfl_xor(vl, o, 64); vf = y < vf ? y : vf; vl = z > vl ? z : vl; }
+			// rows a path of score >= T can span inside L columns
+			const int gaps = 5 * L - T - 12;
+			const int rmax = gaps >= 4 ? L + gaps / 4 : L;
+			int top = (int)r0s[vf] - (rmax - 1); if (top < 0) top = 0;
+			const int bot = (int)r0s[vl + 1];
+			for (int c = 0; c < 3 && chosen < 0; c++) {
+				const int G = 8 << c;
+				if (!((a.class_mask >> c) & 1) || G > a.nl) continue;
+				int q0 = top / 48; if (q0 > a.nl - G) q0 = a.nl - G;
+				const int r0 = 48 * q0, r1 = r0 + 48 * G;
+				if (r1 < bot) continue;                                   // does not reach the last lane that matters
+				int theta = 1;
+				for (int v = lane; v < nv; v += 64) {
+					const int lo = r0s[v], hi = r0s[v + 1], u = ub[v];
+					int tau;
+					if (lo < r0 || hi > r1) tau = u + 1;                 // not entirely inside: must not reach theta
+					else if (r0 == 0) tau = 1;
+					else {
+						const int D = lo - r0 + 1;                         // rows available to a path that ends in this lane
+						const int ts = D >= L ? 9 * L - 4 * D - 15 : 5 * L + 1;
+						tau = u + 1 < ts ? u + 1 : ts;
+					}
+					theta = tau > theta ? tau : theta;
+				}
+				for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(theta, o, 64); theta = y > theta ? y : theta; }
+				if (theta <= T) { chosen = c; ch_q0 = q0; ch_theta = theta; }
+			}
+		}
+		if (lane == 0) { d_cls[slot_k] = chosen; d_q0[slot_k] = ch_q0; d_theta[slot_k] = ch_theta; }
 	}
-	if (chosen < 0) { if (lane == 0) a.out[p].flags = 16; return; }
-	const int nq = (L + 2 + 3) / 4;                            // stream length in groups of 4 columns
-	uint32_t slot = 0;
-	if (lane == 0) { slot = atomicAdd(a.counts + chosen, 1u); atomicAdd(a.counts + 4 + chosen, (uint32_t)(4 * nq)); }
-	slot = (uint32_t)__shfl((int)slot, 0, 64);
-	if (slot >= a.list_cap) { if (lane == 0) a.out[p].flags = 16; return; }      // (cannot happen: the lists hold every try)
-	if (lane == 0) {
-		BandTry bt; bt.prob = p; bt.r0 = 48 * ch_q0; bt.theta_min = ch_theta; bt.nq = nq;
-		a.list[chosen][slot] = bt;
-		a.out[p].flags = 8;
+	__syncthreads();
+	// ---- one slot allocation per class for the whole workgroup
+	if (wv == 0) {
+		const int cls = d_cls[lane];
+		int nq = 0;
+		if (cls >= 0) { const int w = w0 + lane; const int p = a.idx ? a.idx[w] : w; nq = (a.probs[p].len + 2 + 3) / 4; }
+		int myslot = -1;
+		for (int c = 0; c < 3; c++) {
+			const unsigned long long mk = __builtin_amdgcn_ballot_w64(cls == c);
+			if (!mk) continue;
+			int cols = cls == c ? 4 * nq : 0;
+			for (int o = 32; o > 0; o >>= 1) cols += __shfl_xor(cols, o, 64);
+			uint32_t base = 0;
+			if (lane == 0) { base = atomicAdd(a.counts + c, (uint32_t)__popcll(mk)); atomicAdd(a.counts + 4 + c, (uint32_t)cols); }
+			base = (uint32_t)__shfl((int)base, 0, 64);
+			if (cls == c) myslot = (int)base + __popcll(mk & ((1ull << lane) - 1ull));
+		}
+		d_slot[lane] = myslot;
 	}
-	uint16_t* s = a.slots[chosen] + (size_t)slot * BAND_SLOT_COLS;
-	const int lead = 4 * nq - L;
+	__syncthreads();
+	// ---- list entries and column streams
 	const int voidw = BAND_VOID_BIT | (5 * a.nl * 7);
-	for (int k = lane; k < 4 * nq; k += 64) {
-		int word = voidw;
-		if (k >= lead) {
-			const int col = k - lead;
-			int code = a.tcodes[pb.tbase + col]; if (code > 4) code = 4;
-			word = (code * a.nl + ch_q0) * 7;
-			if (col == L - 1) word |= BAND_LAST_BIT;
+	for (int k = 0; k < SEL_TRIES / 4; k++) {
+		const int slot_k = wv * (SEL_TRIES / 4) + k, w = w0 + slot_k;
+		const int cls = d_cls[slot_k];
+		if (cls == -2) continue;
+		const int p = a.idx ? a.idx[w] : w;
+		if (cls < 0 || (uint32_t)d_slot[slot_k] >= a.list_cap) { if (lane == 0) a.out[p].flags = 16; continue; }
+		const FwdProb pb = a.probs[p];
+		const int L = pb.len, nq = (L + 2 + 3) / 4, q0 = d_q0[slot_k];
+		const uint32_t slot = (uint32_t)d_slot[slot_k];
+		if (lane == 0) {
+			BandTry bt; bt.prob = p; bt.r0 = 48 * q0; bt.theta_min = d_theta[slot_k]; bt.nq = nq;
+			a.list[cls][slot] = bt;
+			a.out[p].flags = 8;
 		}
-		s[k] = (uint16_t)word;
+		// two columns per lane and store: 64 lanes cover 128 columns per round
+		uint32_t* s2 = reinterpret_cast<uint32_t*>(a.slots[cls] + (size_t)slot * BAND_SLOT_COLS);
+		const int lead = 4 * nq - L;
+		for (int kk = lane; kk < 2 * nq; kk += 64) {
+			uint32_t word = 0;
+#pragma unroll
+			for (int h = 0; h < 2; h++) {
+				const int pos = 2 * kk + h;
+				int x = voidw;
+				if (pos >= lead) {
+					const int col = pos - lead;
+					int code = a.tcodes[pb.tbase + col]; if (code > 4) code = 4;
+					x = (code * a.nl + q0) * 7;
+					if (col == L - 1) x |= BAND_LAST_BIT;
+				}
+				word |= (uint32_t)x << (16 * h);
+			}
+			s2[kk] = word;
+		}
 	}
 }
 
@@ -177,7 +223,8 @@ hipError_t launch_band_select(const BandSelLaunch& L, hipStream_t st)
 	if (128 * a.ntiles > SEL_MAXV) return hipErrorInvalidValue;
 	hipError_t err = hipMemsetAsync(a.counts, 0, 8 * sizeof(uint32_t), st);
 	if (err != hipSuccess) return err;
-	hipLaunchKernelGGL(k_band_select, dim3((unsigned)((L.n + 3) / 4)), dim3(256), 0, st, a);
+	const size_t lds = (size_t)4 * (2 * 128 * a.ntiles + 2) * sizeof(uint16_t);
+	hipLaunchKernelGGL(k_band_select, dim3((unsigned)((L.n + SEL_TRIES - 1) / SEL_TRIES)), dim3(256), lds, st, a);
 	return hipGetLastError();
 }
 
@@ -230,7 +277,7 @@ __global__ void __launch_bounds__(BAND_THREADS) __attribute__((amdgpu_waves_per_
 	extern __shared__ __align__(16) uint8_t lds[];
 	uint8_t* prof = lds;                                     // [5 codes][nl lanes][112] | void block [G][112]
 	const int code_stride = a.nl * BAND_LANE_STRIDE;
-	uint4* fifo = reinterpret_cast<uint4*>(lds + 5 * code_stride + G * BAND_LANE_STRIDE);     // [wave][NG][BAND_FIFO]
+	uint4* fifo = reinterpret_cast<uint4*>(lds + 5 * code_stride + G * BAND_LANE_STRIDE);     // [wave][NG][G]
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	for (int idx = threadIdx.x; idx < 5 * a.nl * 48; idx += blockDim.x) {
 		const int r = idx % 48, l = (idx / 48) % a.nl, t = idx / (48 * a.nl);
@@ -242,7 +289,8 @@ __global__ void __launch_bounds__(BAND_THREADS) __attribute__((amdgpu_waves_per_
 
 	const int j = lane & (G - 1), grp = lane / G;
 	const bool is_start = j == 0, is_end = j == G - 1;
-	uint4* myfifo = fifo + ((size_t)wv * NG + grp) * BAND_FIFO;
+	constexpr int FIFO = G;
+	uint4* myfifo = fifo + ((size_t)wv * NG + grp) * FIFO;
 	const uint8_t* pl = prof + j * BAND_LANE_STRIDE;
 	// row keys: (column maximum << 16) | (0xFFFF - row relative to the band's first row)
 	const int kbase_lo = 0xFFFF - (2 * j) * BAND_RPB - 31, kbase_hi = 0xFFFF - (2 * j + 1) * BAND_RPB - 31;
@@ -276,7 +324,7 @@ __global__ void __launch_bounds__(BAND_THREADS) __attribute__((amdgpu_waves_per_
 				if (f_idx < a.n) {
 					f_slot = reinterpret_cast<const uint2*>(a.slots + (size_t)f_idx * BAND_SLOT_COLS);
 					f_nq = nbt.nq; f_q = 0;
-					myfifo[n_start & (BAND_FIFO - 1)] = make_uint4((uint32_t)nbt.prob, (uint32_t)nbt.theta_min, (uint32_t)nbt.r0, 0u);
+					myfifo[n_start & (FIFO - 1)] = make_uint4((uint32_t)nbt.prob, (uint32_t)nbt.theta_min, (uint32_t)nbt.r0, 0u);
 					n_start++;
 					f_idx += gstride;
 					if (f_idx < a.n) nbt = a.list[f_idx];
@@ -347,7 +395,7 @@ __global__ void __launch_bounds__(BAND_THREADS) __attribute__((amdgpu_waves_per_
 			const bool emit = is_end && (th & BAND_LAST_BIT) && real;
 			if (__builtin_amdgcn_ballot_w64(emit) != 0ull) {
 				if (emit) {
-					const uint4 fe = myfifo[n_end & (BAND_FIFO - 1)];
+					const uint4 fe = myfifo[n_end & (FIFO - 1)];
 					n_end++;
 					FwdOut o;
 					o.score = runmax; o.ref_end = end_ref;
@@ -363,13 +411,18 @@ __global__ void __launch_bounds__(BAND_THREADS) __attribute__((amdgpu_waves_per_
 }
 
 int band_profile_lanes(int m) { return (16 * ((m + 15) / 16) + 47) / 48; }
-size_t band_lds_bytes(int m, int G) { return (size_t)(5 * band_profile_lanes(m) + G) * BAND_LANE_STRIDE + (size_t)(BAND_THREADS / 64) * (64 / G) * BAND_FIFO * sizeof(uint4); }
-// classes (bit c: G = 8 << c) the band kernel can run for a query of m rows
+size_t band_lds_bytes(int m, int G) { return (size_t)(5 * band_profile_lanes(m) + G) * BAND_LANE_STRIDE + (size_t)(BAND_THREADS / 64) * 64 * sizeof(uint4); }
+// classes (bit c: G = 8 << c) the band kernel runs for a query of m rows: the profile must fit the LDS budget and the band must
+// be at most 3/8 of the query's height (a band of half the height costs more than it saves: measured on H19, G = 32)
 int band_classes(int m)
 {
 	if (!systolic_fits(m) || systolic_tiles(m) > 16) return 0;
 	int mask = 0;
-	for (int c = 0; c < 3; c++) { const int G = 8 << c; if (band_profile_lanes(m) >= 2 * G && band_lds_bytes(m, G) <= 72 * 1024 && (5 * band_profile_lanes(m) + G) * 7 < BAND_VOID_BIT) mask |= 1 << c; }
+	const int nl = band_profile_lanes(m);
+	for (int c = 0; c < 3; c++) {
+		const int G = 8 << c;
+		if (8 * G <= 3 * nl && band_lds_bytes(m, G) <= 72 * 1024 && (5 * nl + G) * 7 < BAND_VOID_BIT) mask |= 1 << c;
+	}
 	return mask;
 }
 
@@ -377,9 +430,13 @@ template <int G>
 static hipError_t launch_band_t(const BandArgs& a, size_t lds, hipStream_t st)
 {
 	constexpr int NG = 64 / G;
-	// about 24 windows per sub-pipeline amortise the fill of the pipeline; never more than two workgroups per CU
-	long groups = ((long)a.n + 23) / 24;
-	long blocks = (groups + (BAND_THREADS / 64) * NG - 1) / ((BAND_THREADS / 64) * NG);
+	// Two workgroups per CU fill the chip (512 of them); a long list gives every sub-pipeline about 24 windows or more (the fill
+	// of its 2 G virtual lanes is then amortised), a short one is spread thin instead (at least 3 windows per sub-pipeline): the
+	// launch is as long as its longest sub-pipeline.
+	constexpr int GPB = (BAND_THREADS / 64) * NG;         // sub-pipelines per workgroup
+	long per = ((long)a.n + 512L * GPB - 1) / (512L * GPB);
+	if (per < 3) per = 3;
+	long blocks = ((long)a.n + per * GPB - 1) / (per * GPB);
 	if (blocks > 512) blocks = 512;
 	if (blocks < 1) blocks = 1;
 	static bool attr_set = false;                   // (benign race: the call is idempotent)

@@ -926,7 +926,7 @@ int run_fwd_band(fasim_engine* E, const UnitBatch& B, const std::vector<WindowPr
 	ProfScope ps(28, "run_fwd_band total");
 	const int mask = band_mask(E);
 	std::vector<FwdProb> probs(n);
-	for (int k = 0; k < n; k++) { probs[k].tbase = (int64_t)W[k].unit * B.tstride + W[k].t0; probs[k].len = W[k].len; probs[k].stream_off = 0; }
+	for (int k = 0; k < n; k++) { probs[k].tbase = (int64_t)W[k].unit * B.tstride + W[k].t0; probs[k].len = W[k].len; probs[k].stream_off = W[k].unit; }      // (stream_off carries the unit here)
 	int rc = upload_async(E, E->fprobs, probs.data(), sizeof(FwdProb) * n); if (rc) return rc;
 	HIPOK(E->fout.ensure(sizeof(FwdOut) * n));
 	HIPOK(E->bcounts.ensure(64));
