@@ -72,27 +72,35 @@ constexpr int CODE_VOID = 4;                 // stream codes: A0 C1 G2 T3, 4 = v
 constexpr int CODE_SN = 5;                   // (the unit codes of kernels.h use 4 for N: k_build_stream re-codes)
 constexpr int TAG_LAST = 8;                  // bit 3 of a stream byte: last column of a window
 constexpr int TAG_HZ = 16;                   // bit 4 (in flight only): hazard seen in this column
+// bits 5-6 of a stream byte: zone = how many of the candidate's LATER window tries (suffixes of this window) hold the column
 
 // ------------------------------------------------------------------------------------------------
 __global__ void k_build_stream(const uint8_t* __restrict__ tcodes, const FwdProb* __restrict__ probs, int32_t nprob,
-	uint8_t* __restrict__ stream)
+	uint8_t* __restrict__ stream, const uint32_t* __restrict__ zones)
 {
 	const int p = blockIdx.x;
 	if (p >= nprob) return;
 	const FwdProb pb = probs[p];
 	uint8_t* s = stream + pb.stream_off;
+	// zones[p] = lengths of the candidate's next three window tries (one byte each, 0 = none): they end in the same column
+	const uint32_t z = zones ? zones[p] : 0u;
+	const int z1 = pb.len - (int)(z & 0xffu), z2 = pb.len - (int)((z >> 8) & 0xffu), z3 = pb.len - (int)((z >> 16) & 0xffu);
 	for (int c = threadIdx.x; c < pb.len + 2; c += blockDim.x) {
 		uint8_t v;
 		if (c < 2) v = CODE_VOID;
-		else { v = tcodes[pb.tbase + (c - 2)]; if (v >= 4) v = CODE_SN; if (c - 2 == pb.len - 1) v |= TAG_LAST; }
+		else {
+			const int col = c - 2;
+			v = tcodes[pb.tbase + col]; if (v >= 4) v = CODE_SN; if (col == pb.len - 1) v |= TAG_LAST;
+			if (z) v |= (uint8_t)((((z & 0xffu) && col >= z1) + (((z >> 8) & 0xffu) && col >= z2) + (((z >> 16) & 0xffu) && col >= z3)) << 5);
+		}
 		s[c] = v;
 	}
 }
 
-hipError_t launch_build_stream(const uint8_t* tcodes, const FwdProb* probs, int32_t nprob, uint8_t* stream, hipStream_t st)
+hipError_t launch_build_stream(const uint8_t* tcodes, const FwdProb* probs, int32_t nprob, uint8_t* stream, const uint32_t* zones, hipStream_t st)
 {
 	if (nprob <= 0) return hipSuccess;
-	hipLaunchKernelGGL(k_build_stream, dim3((unsigned)nprob), dim3(64), 0, st, tcodes, probs, nprob, stream);
+	hipLaunchKernelGGL(k_build_stream, dim3((unsigned)nprob), dim3(64), 0, st, tcodes, probs, nprob, stream, zones);
 	return hipGetLastError();
 }
 
@@ -108,6 +116,9 @@ struct FwdArgs {
 	FwdOut* out;
 	int32_t vs, tile, ntiles;      // query tiling as in scan.hip
 	uint4* boundary;               // [stream position]: {hbot | fbot<<16, fpo | hazard<<16, key, 0} between tiles
+	// bounds for the banded passes of the candidate's later tries (8-bit pass only): per window and zone z = 1..3 the maximum H
+	// of every virtual lane over the columns of zone >= z, written to lane_ub[(ub_slot[prob] * 3 + z - 1) * nv + virtual lane]
+	uint16_t* lane_ub; const int32_t* ub_slot; int32_t nv;
 };
 
 __device__ __forceinline__ void lane_rows_a(int v, int seg_len, int vs, int* row0, int* rows)
@@ -129,33 +140,19 @@ __device__ __forceinline__ int fwd_cell_score(const FwdArgs& a, int t, int v, in
 	return ((q == t && t < 4) ? 5 : -4) * sc;
 }
 
-// pair profile of the PAIR variant (see scan.hip): pairs over {A, C, G, T, void}; an N column is rare and patched in
-constexpr int FP_LANE_STRIDE = 96, FP_GROUP_STRIDE = 8 * FP_LANE_STRIDE + 16, FP_STRIDE = 6400, FP_LDS = 25 * FP_STRIDE;
-__device__ __forceinline__ int fp_lane_offset(int lane) { return (lane >> 3) * FP_GROUP_STRIDE + (lane & 7) * FP_LANE_STRIDE; }
-
-// PAIR = false: 256-thread workgroups, per-code int16 profile (43 KB) + one v_perm_b32 per row;
-// PAIR = true : 1024-thread workgroups, profile per pair of codes (156 KB), no perm
-// workgroup size of the non-PAIR variant: 512 threads = 8 waves share one 43 KB profile, so two workgroups (86 KB) put 4 waves
+// per-code int16 profile (43 KB) + one v_perm_b32 per row
+// workgroup size: 512 threads = 8 waves share one 43 KB profile, so two workgroups (86 KB) put 4 waves
 // on every SIMD; with 256-thread workgroups LDS allowed only three (3 waves per SIMD), and the packed VALU ops issue ~15 %
 // slower at 3 waves per SIMD than at 4 (profiles/r02_valu_issue_bench.txt)
 constexpr int FWD_THREADS = 512;
-template <int RP, bool TAINT, bool PAIR>
-__global__ void __launch_bounds__(PAIR ? 1024 : FWD_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) k_align_fwd(FwdArgs a)
+template <int RP, bool TAINT>
+__global__ void __launch_bounds__(FWD_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) k_align_fwd(FwdArgs a)
 {
 	constexpr int SC = TAINT ? 2 * AL_SCALE : AL_SCALE;      // value scale; TAINT: bit 5 = taint, bits 0..4 = row tag
 	extern __shared__ __align__(16) uint8_t prof[];
 	const int lane = threadIdx.x & 63;
 
-	if constexpr (PAIR) {
-		for (int idx = threadIdx.x; idx < 25 * 64 * 24; idx += blockDim.x) {
-			const int r = idx % 24;
-			const int l = (idx / 24) % 64;
-			const int pr = idx / (24 * 64);
-			const int lo = fwd_cell_score(a, pr / 5, 128 * a.tile + 2 * l, r, SC);
-			const int hi = fwd_cell_score(a, pr % 5, 128 * a.tile + 2 * l + 1, r, SC);
-			*reinterpret_cast<uint32_t*>(prof + pr * FP_STRIDE + fp_lane_offset(l) + r * 4) = ((uint32_t)(uint16_t)(int16_t)lo) | ((uint32_t)(uint16_t)(int16_t)hi << 16);
-		}
-	} else {
+	{
 		for (int idx = threadIdx.x; idx < 6 * 128 * AL_RS; idx += blockDim.x) {
 			const int r = idx % AL_RS;
 			const int v = (idx / AL_RS) % 128;
@@ -169,13 +166,10 @@ __global__ void __launch_bounds__(PAIR ? 1024 : FWD_THREADS) __attribute__((amdg
 	// stripe-aligned layout (see scan.hip): virtual lane 8k starts the reference's stripe k
 	uint32_t fthr = 0xFFFFFFFFu, act = 0, startbits = 0;
 	int row0[2];
-	uint32_t realc = 0, rowsc = 0;               // per half: rows with a real query letter / rows owned (N columns, PAIR)
 	for (int h = 0; h < 2; h++) {
 		const int v = 128 * a.tile + 2 * lane + h;
 		int rows_v;
 		lane_rows_a(v, a.seg_len16, a.vs, &row0[h], &rows_v);
-		const int real = a.m - row0[h] < 0 ? 0 : (a.m - row0[h] > rows_v ? rows_v : a.m - row0[h]);
-		realc |= (uint32_t)real << (16 * h); rowsc |= (uint32_t)rows_v << (16 * h);
 		if (v % a.vs == 0 && v > 0) { fthr = (fthr & ~(0xFFFFu << (16 * h))) | ((131u * SC + (SC - 1)) << (16 * h)); startbits |= 0xFFFFu << (16 * h); }
 		if (rows_v == RP) act |= 0xFFFFu << (16 * h);
 	}
@@ -183,8 +177,7 @@ __global__ void __launch_bounds__(PAIR ? 1024 : FWD_THREADS) __attribute__((amdg
 	const v2u actm = u_from((int)act);
 	const v2u startm = u_from((int)startbits);
 	const bool lvl2 = a.seg_len16 >= 96;      // (the 16-bit pass, !TAINT, needs no Q2 test at all: its compare is unaffected)
-	const int pl_off = PAIR ? fp_lane_offset(lane) : lane * AL_LANE_STRIDE;
-	const uint8_t* pl = prof + pl_off;
+	const uint8_t* pl = prof + lane * AL_LANE_STRIDE;
 	// (31 - r) tags for the row keys, and the base of the global-row key of my two virtual lanes
 	const int kbase_lo = 0xFFFF - row0[0] - 31, kbase_hi = 0xFFFF - row0[1] - 31;
 
@@ -212,6 +205,7 @@ __global__ void __launch_bounds__(PAIR ? 1024 : FWD_THREADS) __attribute__((amdg
 		int chunk = CODE_VOID;
 		// pipe-end state (meaningful in lane 63)
 		int pidx = p0, cidx = 0, runmax = 0, end_ref = -1, end_read = 0, hzflag = 0, over = 0, wtaint = 0;
+		v2u zacc1 = (v2u){ 0, 0 }, zacc2 = (v2u){ 0, 0 }, zacc3 = (v2u){ 0, 0 }, wcnt = (v2u){ 0, 0 };      // zone maxima of my two virtual lanes; windows they have finished
 		const int nsteps = slen + 127;
 		for (int step = 0; step < nsteps; step++) {
 			if ((step & 63) == 0) {
@@ -246,29 +240,10 @@ __global__ void __launch_bounds__(PAIR ? 1024 : FWD_THREADS) __attribute__((amdg
 			recv_h_last = recv_h;
 			v2u f = u_from(recv_f);
 			v2s lkx[4] = { (v2s){ 0, 0 }, (v2s){ 0, 0 }, (v2s){ 0, 0 }, (v2s){ 0, 0 } };      // independent max chains
-			constexpr int ROWS_PER_LOAD = PAIR ? 4 : 8;
+			constexpr int ROWS_PER_LOAD = 8;
 			constexpr int NLOAD = (RP + ROWS_PER_LOAD - 1) / ROWS_PER_LOAD;
 			v4i PA[NLOAD], PB[NLOAD];
-			if constexpr (PAIR) {
-				// pair index = min(code, 4) of the two halves (an N half borrows the void rows and is patched below)
-				const v2u pc = __builtin_elementwise_min(tt, (v2u){ 4, 4 });
-				const uint8_t* pp = prof + __builtin_amdgcn_udot2(pc, (v2u){ 5 * FP_STRIDE, FP_STRIDE }, (unsigned)pl_off, false);
-#pragma unroll
-				for (int g = 0; g < NLOAD; g++) { PA[g] = *reinterpret_cast<const v4i*>(pp + 16 * g); PB[g] = PA[g]; }
-				const v2u isn = __builtin_elementwise_sub_sat(tt, (v2u){ 4, 4 });    // 1 where the half sits on an N column
-				if (__builtin_amdgcn_ballot_w64(a_i(isn) != 0) != 0ull) {
-					// N scores -4 against every real row, 0 against the pad rows, and rows beyond the half's share stay dead
-					const v2u nmask = (v2u){ 0, 0 } - isn;
-#pragma unroll
-					for (int r = 0; r < RP; r++) {
-						const v2u isreal = __builtin_elementwise_min(__builtin_elementwise_sub_sat(u_from((int)realc), (v2u){ (unsigned short)r, (unsigned short)r }), (v2u){ 1, 1 });
-						const v2u islive = __builtin_elementwise_min(__builtin_elementwise_sub_sat(u_from((int)rowsc), (v2u){ (unsigned short)r, (unsigned short)r }), (v2u){ 1, 1 });
-						const v2u nsc = (isreal * (v2u){ (unsigned short)(-4 * SC), (unsigned short)(-4 * SC) }) | ((islive - (v2u){ 1, 1 }) & (v2u){ 0x8000, 0x8000 });
-						const int g = r >> 2, k = r & 3;
-						PA[g][k] = (int)(((uint32_t)PA[g][k] & ~(uint32_t)a_i(nmask)) | ((uint32_t)a_i(nsc) & (uint32_t)a_i(nmask)));
-					}
-				}
-			} else {
+			{
 				const int t_lo = tc & 7, t_hi = (tc >> 16) & 7;
 				const uint8_t* pa = pl + t_lo * AL_CODE_STRIDE;
 				const uint8_t* pb = pl + t_hi * AL_CODE_STRIDE + 48;
@@ -279,8 +254,7 @@ __global__ void __launch_bounds__(PAIR ? 1024 : FWD_THREADS) __attribute__((amdg
 				}
 			}
 			auto score_of = [&](int r) -> int {
-				if constexpr (PAIR) return PA[r >> 2][r & 3];
-				else { const int g = r >> 3, k = r & 7; return __builtin_amdgcn_perm(PB[g][k >> 1], PA[g][k >> 1], (k & 1) ? 0x07060302 : 0x05040100); }
+				const int g = r >> 3, k = r & 7; return __builtin_amdgcn_perm(PB[g][k >> 1], PA[g][k >> 1], (k & 1) ? 0x07060302 : 0x05040100);
 			};
 			// (see scan.hip: the diagonal sum goes into the register of the score, the new H into the register of the old
 			//  H, so the H column needs no second copy and no moves at the end of the step)
@@ -315,6 +289,33 @@ __global__ void __launch_bounds__(PAIR ? 1024 : FWD_THREADS) __attribute__((amdg
 			const v2s lkey = __builtin_elementwise_max(__builtin_elementwise_max(lkx[0], lkx[1]), __builtin_elementwise_max(lkx[2], lkx[3]));
 			asm volatile("" :: "v"(a_i(lkey)));      // pin the reduction before the hazard branch (see scan.hip)
 			fbot = a_i(f);
+			if constexpr (TAINT) {
+				if (a.lane_ub) {
+					// my two columns' maxima (value = key >> 6) go into the running maxima of the zones that hold the column
+					const v2u tcu = u_from(tc);
+					const v2u zz = (tcu >> (v2u){ 5, 5 }) & (v2u){ 3, 3 };
+					const v2u val = a_u(lkey) >> (v2u){ 6, 6 };
+					zacc1 = __builtin_elementwise_max(zacc1, val & ((v2u){ 0, 0 } - __builtin_elementwise_min(zz, (v2u){ 1, 1 })));
+					zacc2 = __builtin_elementwise_max(zacc2, val & ((v2u){ 0, 0 } - __builtin_elementwise_min(__builtin_elementwise_sub_sat(zz, (v2u){ 1, 1 }), (v2u){ 1, 1 })));
+					zacc3 = __builtin_elementwise_max(zacc3, val & ((v2u){ 0, 0 } - __builtin_elementwise_sub_sat(zz, (v2u){ 2, 2 })));
+					const v2u lastb = (tcu >> (v2u){ 3, 3 }) & (v2u){ 1, 1 };
+					if (__builtin_amdgcn_ballot_w64(a_i(lastb) != 0) != 0ull) {
+#pragma unroll
+						for (int h = 0; h < 2; h++) {
+							if (lastb[h]) {
+								const int slot = a.ub_slot[p0 + (int)wcnt[h]];
+								if (slot >= 0) {
+									uint16_t* o = a.lane_ub + (size_t)slot * 3 * a.nv + 128 * a.tile + 2 * lane + h;
+									o[0] = zacc1[h]; o[a.nv] = zacc2[h]; o[2 * (size_t)a.nv] = zacc3[h];
+								}
+							}
+						}
+						const v2u keep = lastb - (v2u){ 1, 1 };
+						zacc1 &= keep; zacc2 &= keep; zacc3 &= keep;
+						wcnt += lastb;
+					}
+				}
+			}
 			// Q2 (8-bit pass only).  Short queries: any F[b] >= 132 entering a stripe flags the column (TAG_HZ).  Otherwise the
 			// row analysis of scan.hip marks the cells the reference's early lazy-F exit would have left smaller (taint bit).
 			fpo = 0;
@@ -414,24 +415,16 @@ __global__ void __launch_bounds__(PAIR ? 1024 : FWD_THREADS) __attribute__((amdg
 	}
 }
 
-template <int RP, bool TAINT, bool PAIR>
+template <int RP, bool TAINT>
 static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st)
 {
 	hipError_t err = hipMemsetAsync(a.counter, 0, sizeof(uint32_t), st);
 	if (err != hipSuccess) return err;
 	// (the host sizes the tasks so that there are about 3072 of them: one task per wave, workgroups are short-lived)
-	// FASIM_FWD_THREADS=256 restores the round-1 shape (4 waves per workgroup, LDS then allows 3 workgroups = 3 waves per SIMD)
-	static const int fwd_threads = [] { const char* e = getenv("FASIM_FWD_THREADS"); const int v = e ? atoi(e) : FWD_THREADS; return (v == 256 || v == 512) ? v : FWD_THREADS; }();
-	const int WPB = PAIR ? 16 : fwd_threads / 64;
+	constexpr int WPB = FWD_THREADS / 64;
 	long blocks = ((long)a.ntask + WPB - 1) / WPB;
-	const long cap = PAIR ? 256 : (WPB == 4 ? 256 * 3 : 256 * 2);
-	if (blocks > cap) blocks = cap;
-	const size_t lds = PAIR ? (size_t)FP_LDS : (size_t)6 * AL_CODE_STRIDE;
-	if (PAIR) {
-		static bool attr_set = false;
-		if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_align_fwd<RP, TAINT, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-	}
-	hipLaunchKernelGGL((k_align_fwd<RP, TAINT, PAIR>), dim3((unsigned)blocks), dim3(PAIR ? 1024 : fwd_threads), lds, st, a);
+	if (blocks > 256 * 2) blocks = 256 * 2;
+	hipLaunchKernelGGL((k_align_fwd<RP, TAINT>), dim3((unsigned)blocks), dim3(FWD_THREADS), (size_t)6 * AL_CODE_STRIDE, st, a);
 	return hipGetLastError();
 }
 
@@ -443,15 +436,14 @@ hipError_t launch_align_fwd(const FwdLaunch& L, hipStream_t st)
 	a.stream = L.stream; a.probs = L.probs; a.task_first = L.task_first; a.ntask = L.ntask; a.counter = L.counter;
 	a.qcodes = L.qcodes; a.m = L.m; a.m_pad = 16 * ((L.m + 15) / 16); a.seg_len16 = (L.m + 15) / 16; a.out = L.out;
 	a.vs = systolic_vs(L.m); a.ntiles = a.vs / 8; a.boundary = L.boundary;
+	a.lane_ub = L.word ? nullptr : L.lane_ub; a.ub_slot = L.ub_slot; a.nv = 128 * a.ntiles;
 	if (a.ntiles > 1 && !a.boundary) return hipErrorInvalidValue;
 	const int rp = (a.seg_len16 + a.vs - 1) / a.vs;
-	static const bool pair = [] { const char* e = getenv("FASIM_FWD_PAIR"); return e ? atoi(e) != 0 : false; }();   // off: see DESIGN.md
 	for (int t = 0; t < a.ntiles; t++) {
 		a.tile = t;
 		hipError_t err = hipErrorInvalidValue;
 		switch (rp) {
-#define FASIM_FWD_CASE(N) case N: err = pair ? (L.word ? launch_fwd_t<N, false, true>(a, st) : launch_fwd_t<N, true, true>(a, st)) \
-                                             : (L.word ? launch_fwd_t<N, false, false>(a, st) : launch_fwd_t<N, true, false>(a, st)); break;
+#define FASIM_FWD_CASE(N) case N: err = L.word ? launch_fwd_t<N, false>(a, st) : launch_fwd_t<N, true>(a, st); break;
 		FASIM_FWD_CASE(1) FASIM_FWD_CASE(2) FASIM_FWD_CASE(3) FASIM_FWD_CASE(4) FASIM_FWD_CASE(5) FASIM_FWD_CASE(6)
 		FASIM_FWD_CASE(7) FASIM_FWD_CASE(8) FASIM_FWD_CASE(9) FASIM_FWD_CASE(10) FASIM_FWD_CASE(11) FASIM_FWD_CASE(12)
 		FASIM_FWD_CASE(13) FASIM_FWD_CASE(14) FASIM_FWD_CASE(15) FASIM_FWD_CASE(16) FASIM_FWD_CASE(17) FASIM_FWD_CASE(18)

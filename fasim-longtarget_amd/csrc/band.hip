@@ -60,6 +60,7 @@ struct BandSelArgs {
 	const FwdProb* probs; const int32_t* target; const int32_t* idx;   // idx: NULL = tries 0..n-1, else the tries to look at
 	int32_t n, tstride;
 	const uint32_t* ublk; int32_t ublk_blocks, ntiles;
+	const uint16_t* prev_ub; const int32_t* prev;      // bounds from an earlier full-height pass of the candidate (see kernels.h)
 	int32_t m, seg16, vs, nl;            // nl = lanes of the band profile = ceil(16 * seg16 / 48)
 	const uint8_t* tcodes;
 	BandTry* list[3]; uint16_t* slots[3]; uint32_t list_cap;
@@ -94,6 +95,8 @@ __global__ void __launch_bounds__(256) k_band_select(BandSelArgs a)
 		__builtin_amdgcn_wave_barrier();
 		// ---- upper bounds per virtual lane of k_scan: the blocks of steps [t0 + v, pe + v] (v = lane index inside the tile)
 		int umax = 0;
+		const int pv = a.prev ? a.prev[w] : -1;
+		const uint16_t* PU = pv >= 0 ? a.prev_ub + ((size_t)(pv >> 2) * 3 + ((pv & 3) - 1)) * nv : nullptr;
 		for (int i = 0; i < a.ntiles; i++) {
 			const uint32_t* U = a.ublk + (((size_t)unit * a.ntiles + i) * a.ublk_blocks) * 64 + lane;
 			const int b0 = (t0 + 2 * lane) / SCAN_UBLK_STEPS;
@@ -111,6 +114,12 @@ __global__ void __launch_bounds__(256) k_band_select(BandSelArgs a)
 			}
 			if (u0 > 5 * L) u0 = 5 * L;
 			if (u1 > 5 * L) u1 = 5 * L;
+			if (PU) {
+				// H of this try <= H of the earlier, longer window of the same candidate, column by column
+				const uint32_t y = *reinterpret_cast<const uint32_t*>(PU + 128 * i + 2 * lane);
+				const int p0 = (int)(y & 0xffffu), p1 = (int)(y >> 16);
+				u0 = p0 < u0 ? p0 : u0; u1 = p1 < u1 ? p1 : u1;
+			}
 			ub[128 * i + 2 * lane] = (uint16_t)u0; ub[128 * i + 2 * lane + 1] = (uint16_t)u1;
 			umax = u0 > umax ? u0 : umax; umax = u1 > umax ? u1 : umax;
 		}
@@ -218,6 +227,7 @@ hipError_t launch_band_select(const BandSelLaunch& L, hipStream_t st)
 	BandSelArgs a;
 	a.probs = L.probs; a.target = L.target; a.idx = L.idx; a.n = L.n; a.tstride = L.tstride; a.ublk = L.ublk; a.ublk_blocks = L.ublk_blocks;
 	a.m = L.m; a.seg16 = (L.m + 15) / 16; a.vs = systolic_vs(L.m); a.ntiles = a.vs / 8; a.nl = band_profile_lanes(L.m);
+	a.prev_ub = L.prev_ub; a.prev = L.prev_ub ? L.prev : nullptr;
 	a.tcodes = L.tcodes; a.list_cap = L.list_cap; a.counts = L.counts; a.out = L.out; a.class_mask = L.class_mask;
 	for (int c = 0; c < 3; c++) { a.list[c] = L.list[c]; a.slots[c] = L.slots[c]; }
 	if (128 * a.ntiles > SEL_MAXV) return hipErrorInvalidValue;

@@ -127,7 +127,7 @@ struct fasim_engine {
 	int64_t kernel_launches[FASIM_KERNEL_FAMILIES] = { 0 };
 	// banded stage 3 (band.hip): block maxima left by the last main k_scan pass of this engine, lists and column streams of the
 	// tries selected per band class
-	DevBuf ublk, btarget, bidx, bcounts, blist[3], bslots[3];
+	DevBuf ublk, btarget, bidx, bcounts, blist[3], bslots[3], bprev, lane_ub, fzones, fubslot;
 	int ublk_units = 0, ublk_blocks = 0;         // units covered by `ublk` (0: none), blocks per (unit, tile)
 	const uint32_t* ub_view = nullptr;           // (as tc_view) the block maxima of the batch's owner during a stolen sub-task
 	int opt_band = -1;                           // option "band": 0 off, 1 on (-1 = default / environment FASIM_BAND)
@@ -698,7 +698,10 @@ static inline const uint8_t* tcv(const fasim_engine* E) { return E->tc_view ? E-
 int run_finish(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, const std::vector<FwdOut>& fo,
 	std::vector<AlignResult>& out, std::vector<uint32_t>& cigars, std::vector<char>& status);
 bool align_v2_fits(const fasim_engine* E, const std::vector<WindowProb>& W);
-int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, std::vector<FwdOut>& fo, bool word);
+// what the 8-bit full-height forward pass leaves for the banded passes of the candidates' later tries (band.hip): per window
+// the lengths of the next three tries (zone tags of the stream) and the slot of the candidate in E->lane_ub (-1: none)
+struct FwdZones { std::vector<uint32_t> zones; std::vector<int32_t> slot; };
+int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, std::vector<FwdOut>& fo, bool word, const FwdZones* Z = nullptr);
 
 // a9-a11: ssw_align for a list of windows (forward + reverse on the GPU, 16-bit re-runs, banded traceback)
 int run_align(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, std::vector<AlignResult>& out,
@@ -849,7 +852,7 @@ bool align_v2_fits(const fasim_engine* E, const std::vector<WindowProb>& W)
 // forward pass of every window (k_build_stream + k_align_fwd): score, ref_end, read_end, hazard flag
 // word = false: the reference's 8-bit pass (taint-tracking kernel; scores from 251 on only mean "overflow");
 // word = true : its 16-bit pass (plain kernel, exact scores up to 980, flags always 0)
-int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, std::vector<FwdOut>& fo, bool word)
+int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, std::vector<FwdOut>& fo, bool word, const FwdZones* Z)
 {
 	const int n = (int)W.size();
 	fo.resize(n);
@@ -868,18 +871,24 @@ int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& 
 	tasks.push_back(n);
 	double tp = now_s();
 	int rc = upload_async(E, E->fprobs, probs.data(), sizeof(FwdProb) * n); if (rc) return rc;      // (both vectors outlive the
+	const bool emit = Z && !word && E->lane_ub.p && (int)Z->zones.size() == n && (int)Z->slot.size() == n;
+	if (emit) {
+		rc = upload_async(E, E->fzones, Z->zones.data(), sizeof(uint32_t) * n); if (rc) return rc;
+		rc = upload_async(E, E->fubslot, Z->slot.data(), sizeof(int32_t) * n); if (rc) return rc;
+	}
 	rc = upload(E, E->ftasks, tasks.data(), sizeof(int32_t) * tasks.size()); if (rc) return rc;          //  synchronisation in here)
 	g_prof.add(1, "run_fwd upload", now_s() - tp);
 	HIPOK(E->fstream.ensure((size_t)off + 256));
 	HIPOK(E->fout.ensure(sizeof(FwdOut) * n));
 	GateScope gate(E);
 	if (E->st_heavy != E->st) HIPOK(hipStreamSynchronize(E->st));
-	hipError_t he = launch_build_stream(tcv(E), E->fprobs.as<FwdProb>(), n, E->fstream.as<uint8_t>(), E->st_heavy);
+	hipError_t he = launch_build_stream(tcv(E), E->fprobs.as<FwdProb>(), n, E->fstream.as<uint8_t>(), emit ? E->fzones.as<uint32_t>() : nullptr, E->st_heavy);
 	if (he != hipSuccess) return fail(E, FASIM_E_HIP, "build_stream launch failed: %s", hipGetErrorString(he));
 	FwdLaunch L;
 	L.stream = E->fstream.as<uint8_t>(); L.probs = E->fprobs.as<FwdProb>(); L.task_first = E->ftasks.as<int32_t>();
 	L.ntask = (int)tasks.size() - 1; L.counter = E->counter.as<uint32_t>(); L.qcodes = E->q2.as<uint8_t>(); L.m = E->m;
 	L.out = E->fout.as<FwdOut>(); L.word = word ? 1 : 0;
+	if (emit) { L.lane_ub = E->lane_ub.as<uint16_t>(); L.ub_slot = E->fubslot.as<int32_t>(); }
 	L.boundary = nullptr;
 	if (systolic_tiles(E->m) > 1) { HIPOK(E->fboundary.ensure(((size_t)off + 256) * sizeof(uint4))); L.boundary = E->fboundary.as<uint4>(); }
 	{ TimedScope ts(E, 2, E->st_heavy); he = launch_align_fwd(L, E->st_heavy); }
@@ -899,9 +908,9 @@ int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& 
 // kernel, which then repeats the whole alignment with its 16-bit kernels (sswNew.cpp:1473-1477, no overflow rule,
 // unsigned-safe compare) -> second pass with the plain systolic kernel for those windows (flags = 4).  A window
 // whose winning cell is tainted (flags & 1) is not trusted either way: the caller replays it exactly.
-int run_fwd_both(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, std::vector<FwdOut>& fo, int64_t* word_reruns)
+int run_fwd_both(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, std::vector<FwdOut>& fo, int64_t* word_reruns, const FwdZones* Z = nullptr)
 {
-	int rc = run_fwd(E, B, W, fo, false); if (rc) return rc;
+	int rc = run_fwd(E, B, W, fo, false, Z); if (rc) return rc;
 	std::vector<int> ov;
 	for (size_t i = 0; i < fo.size(); i++) if (!(fo[i].flags & 1) && fo[i].score >= 255 - BIAS) ov.push_back((int)i);
 	if (ov.empty()) return FASIM_OK;
@@ -918,7 +927,7 @@ int run_fwd_both(fasim_engine* E, const UnitBatch& B, const std::vector<WindowPr
 // the bands; a try whose band came back below its theta_min gets a second band chosen for the score it did reach (a lower
 // bound of the true score).  On return fo[k].flags & 24 marks the tries that still need the full-height kernel.
 int run_fwd_band(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, const std::vector<int32_t>& target,
-	std::vector<FwdOut>& fo, fasim_scan_stats* st)
+	const std::vector<int32_t>* prev, std::vector<FwdOut>& fo, fasim_scan_stats* st)
 {
 	const int n = (int)W.size();
 	fo.resize(n);
@@ -936,19 +945,23 @@ int run_fwd_band(fasim_engine* E, const UnitBatch& B, const std::vector<WindowPr
 		HIPOK(E->bslots[c].ensure(sizeof(uint16_t) * BAND_SLOT_COLS * (size_t)n));
 	}
 	static const bool second = [] { const char* e = getenv("FASIM_BAND_SECOND"); return e ? atoi(e) != 0 : true; }();
-	std::vector<int32_t> idx, tgt2;
+	std::vector<int32_t> idx, tgt2, prev2;
+	const bool have_prev = prev && (int)prev->size() == n && E->lane_ub.p;
 	for (int pass = 0; pass < (second ? 2 : 1); pass++) {
 		int np = n;
 		const int32_t* tsrc = target.data();
+		const int32_t* psrc = have_prev ? prev->data() : nullptr;
 		if (pass == 1) {
 			idx.clear(); tgt2.clear();
-			for (int k = 0; k < n; k++) if (fo[k].flags == 8 && fo[k].score > 0) { idx.push_back(k); tgt2.push_back(fo[k].score); }
-			np = (int)idx.size(); tsrc = tgt2.data();
+			for (int k = 0; k < n; k++) if (fo[k].flags == 8 && fo[k].score > 0) { idx.push_back(k); tgt2.push_back(fo[k].score); if (have_prev) prev2.push_back((*prev)[k]); }
+			np = (int)idx.size(); tsrc = tgt2.data(); if (have_prev) psrc = prev2.data();
 			if (!np) break;
 			rc = upload_async(E, E->bidx, idx.data(), sizeof(int32_t) * np); if (rc) return rc;
 		}
 		rc = upload_async(E, E->btarget, tsrc, sizeof(int32_t) * np); if (rc) return rc;
+		if (psrc) { rc = upload_async(E, E->bprev, psrc, sizeof(int32_t) * np); if (rc) return rc; }
 		BandSelLaunch S;
+		if (psrc) { S.prev_ub = E->lane_ub.as<uint16_t>(); S.prev = E->bprev.as<int32_t>(); }
 		S.probs = E->fprobs.as<FwdProb>(); S.target = E->btarget.as<int32_t>(); S.idx = pass ? E->bidx.as<int32_t>() : nullptr; S.n = np; S.tstride = B.tstride;
 		S.ublk = E->ub_view ? E->ub_view : E->ublk.as<uint32_t>(); S.ublk_blocks = E->ublk_blocks; S.m = E->m; S.tcodes = tcv(E);
 		for (int c = 0; c < 3; c++) { S.list[c] = E->blist[c].as<BandTry>(); S.slots[c] = E->bslots[c].as<uint16_t>(); }
@@ -980,21 +993,29 @@ int run_fwd_band(fasim_engine* E, const UnitBatch& B, const std::vector<WindowPr
 }
 
 // forward pass of a round of tries: banded where the block maxima of k_scan prove a band, full height otherwise
+// prev (optional): per try slot * 4 + zone of the bounds an earlier full-height pass of the candidate left, or -1;
+// Z (optional): zones / slots for the bounds this round's full-height pass leaves; went_full[k] = 1 where try k took that pass
+bool band_ready(const fasim_engine* E, const UnitBatch& B) { return band_mask(E) != 0 && (E->ub_view || E->ublk_units >= B.nunit) && E->ublk_blocks > 0; }
 int run_fwd_smart(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, const std::vector<int32_t>& target,
-	std::vector<FwdOut>& fo, fasim_scan_stats& st)
+	const std::vector<int32_t>* prev, const FwdZones* Z, std::vector<FwdOut>& fo, std::vector<char>* went_full, fasim_scan_stats& st)
 {
-	const bool band = band_mask(E) != 0 && (E->ub_view || E->ublk_units >= B.nunit) && E->ublk_blocks > 0;
-	if (!band) {
+	if (went_full) went_full->assign(W.size(), 0);
+	if (!band_ready(E, B)) {
 		for (const WindowProb& w : W) st.cells_stage3 += (int64_t)E->m * w.len;
 		return run_fwd_both(E, B, W, fo, &st.align_word_reruns);
 	}
-	int rc = run_fwd_band(E, B, W, target, fo, &st); if (rc) return rc;
+	int rc = run_fwd_band(E, B, W, target, prev, fo, &st); if (rc) return rc;
 	std::vector<int> rest;
 	for (size_t k = 0; k < fo.size(); k++) if (fo[k].flags & 24) rest.push_back((int)k);
 	if (rest.empty()) return FASIM_OK;
 	std::vector<WindowProb> W3(rest.size()); std::vector<FwdOut> f3;
-	for (size_t r = 0; r < rest.size(); r++) { W3[r] = W[rest[r]]; st.cells_stage3 += (int64_t)E->m * W3[r].len; }
-	rc = run_fwd_both(E, B, W3, f3, &st.align_word_reruns); if (rc) return rc;
+	FwdZones Z3;
+	for (size_t r = 0; r < rest.size(); r++) {
+		W3[r] = W[rest[r]]; st.cells_stage3 += (int64_t)E->m * W3[r].len;
+		if (Z) { Z3.zones.push_back(Z->zones[rest[r]]); Z3.slot.push_back(Z->slot[rest[r]]); }
+		if (went_full) (*went_full)[rest[r]] = 1;
+	}
+	rc = run_fwd_both(E, B, W3, f3, &st.align_word_reruns, Z ? &Z3 : nullptr); if (rc) return rc;
 	for (size_t r = 0; r < rest.size(); r++) fo[rest[r]] = f3[r];
 	return FASIM_OK;
 }
@@ -1287,7 +1308,8 @@ void fasim_engine_destroy(fasim_engine* e)
 		&e->fprobs, &e->ftasks, &e->fstream, &e->fout, &e->aout, &e->cigpool, &e->cigcount, &e->forder, &e->scratch2, &e->boundary, &e->fboundary, &e->unit_hz,
 		&e->unit_first, &e->hz_cols, &e->hz_plan, &e->hz_base, &e->hz_items, &e->snap, &e->hz_state, &e->hz_rows, &e->hz_chunk, &e->hz_src, &e->hz_zero,
 		&e->qsim, &e->sim_min, &e->sim_row, &e->sim_ev, &e->sim_cnt, &e->sim_nodes,
-		&e->ublk, &e->btarget, &e->bidx, &e->bcounts, &e->blist[0], &e->blist[1], &e->blist[2], &e->bslots[0], &e->bslots[1], &e->bslots[2] };
+		&e->ublk, &e->btarget, &e->bidx, &e->bcounts, &e->blist[0], &e->blist[1], &e->blist[2], &e->bslots[0], &e->bslots[1], &e->bslots[2],
+		&e->bprev, &e->lane_ub, &e->fzones, &e->fubslot };
 	for (auto& t : e->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
 	for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
 	for (DevBuf* b : bufs) b->release();
@@ -1852,7 +1874,7 @@ int stage3_range(fasim_engine* E, BatchCtx& C, int ua, int ub, fasim_scan_stats&
 		//      the reference's layout-dependent behaviour, or whose traceback fails in the reference (NULL ->
 		//      score 0 -> the loop would have continued), are replayed try by try on the stripe-faithful path.
 		t0 = now_s();
-		struct CandState { int unit; Cand c; AlignResult al, best; FwdOut fsel, fbest; int cut, bestcut; char done, flag, exact; };
+		struct CandState { int unit; Cand c; AlignResult al, best; FwdOut fsel, fbest; int cut, bestcut; char done, flag, exact, ub_it; };
 		std::vector<uint32_t> cigars;
 		std::vector<CandState> cs;
 		{
@@ -1867,7 +1889,7 @@ int stage3_range(fasim_engine* E, BatchCtx& C, int ua, int ub, fasim_scan_stats&
 				for (int u = u0; u < u1; u++) {
 					pick_candidates(hits.data() + hoff[u], hcnt[u], tmp);
 					for (const Cand& c : tmp) { CandState x; memset(&x.fsel, 0, sizeof x.fsel); memset(&x.fbest, 0, sizeof x.fbest);
-						x.unit = u; x.c = c; x.done = 0; x.cut = 0; x.bestcut = 0; x.flag = 0; x.exact = 0; part[ti].push_back(x); }
+						x.unit = u; x.c = c; x.done = 0; x.cut = 0; x.bestcut = 0; x.flag = 0; x.exact = 0; x.ub_it = -1; part[ti].push_back(x); }
 				}
 			};
 			if (nt == 1) work(0);
@@ -1880,6 +1902,11 @@ int stage3_range(fasim_engine* E, BatchCtx& C, int ua, int ub, fasim_scan_stats&
 		st.candidates += (int64_t)cs.size();
 		bool v2 = true;
 		{ std::vector<WindowProb> probe(1, WindowProb{ 0, 0, 1 }); v2 = align_v2_fits(E, probe); }
+		// lane maxima left by the full-height passes (bounds for the banded passes of the candidates' later tries): [candidate][3][lanes]
+		static const bool zone_bounds = [] { const char* e = getenv("FASIM_BAND_ZONES"); return e ? atoi(e) != 0 : true; }();
+		const bool zb = v2 && zone_bounds && band_ready(E, B) && !cs.empty() &&
+			E->lane_ub.ensure((size_t)cs.size() * 3 * 128 * systolic_tiles(E->m) * sizeof(uint16_t)) == hipSuccess;
+		if (v2 && !zb) { (void)hipGetLastError(); E->lane_ub.release(); }
 		if (v2) {
 			for (int it = 0; it < 4; it++) {
 				std::vector<WindowProb> W; std::vector<int> who;
@@ -1896,13 +1923,22 @@ int stage3_range(fasim_engine* E, BatchCtx& C, int ua, int ub, fasim_scan_stats&
 				// what the try is expected to score: the candidate's own score at the first try (an accepted try reaches it), a
 				// fraction of the previous try's score afterwards (the windows shrink)
 				static const int rho = [] { const char* e = getenv("FASIM_BAND_RHO"); const int v = e ? atoi(e) : 85; return v < 10 ? 10 : (v > 100 ? 100 : v); }();
-				std::vector<int32_t> target(W.size());
+				std::vector<int32_t> target(W.size()), prev(zb ? W.size() : 0);
+				FwdZones Z;
+				if (zb) { Z.zones.resize(W.size()); Z.slot.resize(W.size()); }
 				for (size_t i = 0; i < who.size(); i++) {
 					const CandState& x = cs[who[i]];
 					target[i] = it == 0 ? x.c.score : std::max(1, x.fsel.score * rho / 100);
+					if (zb) {
+						prev[i] = x.ub_it >= 0 ? who[i] * 4 + (it - x.ub_it) : -1;
+						uint32_t z = 0;
+						for (int j = 1; j <= 3 && it + j < 4; j++) { int cut; if (window_for_try(it + j, x.c.score, x.c.pos, &cut) && cut <= 255) z |= (uint32_t)cut << (8 * (j - 1)); }
+						Z.zones[i] = z; Z.slot[i] = who[i];
+					}
 				}
-				std::vector<FwdOut> fo;
-				rc = run_fwd_smart(E, B, W, target, fo, st); if (rc) return rc;
+				std::vector<FwdOut> fo; std::vector<char> went_full;
+				rc = run_fwd_smart(E, B, W, target, zb ? &prev : nullptr, zb ? &Z : nullptr, fo, &went_full, st); if (rc) return rc;
+				if (zb) for (size_t i = 0; i < who.size(); i++) if (went_full[i]) cs[who[i]].ub_it = (char)it;
 				std::vector<int> fwd_score(fo.size());
 				for (size_t i = 0; i < fo.size(); i++) fwd_score[i] = fo[i].score;
 				{
