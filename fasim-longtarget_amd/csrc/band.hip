@@ -21,6 +21,7 @@
 // Windows in which any bound reaches 148 can meet the reference's Q2 / overflow behaviour and are not banded.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 #include "kernels.h"
 
 namespace fasim {
@@ -54,7 +55,7 @@ __device__ __forceinline__ void scan_lane_rows(int v, int seg_len, int vs, int* 
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_band_select
+// k_band_decide / k_band_emit
 // ------------------------------------------------------------------------------------------------
 struct BandSelArgs {
 	const FwdProb* probs; const int32_t* target; const int32_t* idx;   // idx: NULL = tries 0..n-1, else the tries to look at
@@ -62,21 +63,44 @@ struct BandSelArgs {
 	const uint32_t* ublk; int32_t ublk_blocks, ntiles;
 	const uint16_t* prev_ub; const int32_t* prev;      // bounds from an earlier full-height pass of the candidate (see kernels.h)
 	int32_t m, seg16, vs, nl;            // nl = lanes of the band profile = ceil(16 * seg16 / 48)
+	int32_t zs;                          // zone stride in profile lanes: a band that starts in [z * zs, (z + 1) * zs) belongs to zone z
 	const uint8_t* tcodes;
 	BandTry* list[3]; uint16_t* slots[3]; uint32_t list_cap;
-	uint32_t* counts;                    // [0..2] tries per class, [4..6] stream columns per class
+	int4* dec;                           // [n]: {class or -1, first lane of the band, theta_min, slot}
+	uint32_t* counts;                    // BAND_COUNTS entries, see kernels.h
+	uint32_t* cursors;                   // [3][BAND_MAX_ZONES]: next free slot of every (class, zone) segment of the lists
 	FwdOut* out;
 	int32_t class_mask;                  // bit c: class c (G = 8 << c) may be used
+	int32_t debug;
 };
 
 constexpr int SEL_MAXV = 2048;           // 16 tiles x 128 virtual lanes
-constexpr int SEL_TRIES = 64;            // tries per workgroup (16 per wave): ONE slot allocation per class and workgroup
+constexpr int SEL_TRIES = 64;            // tries per workgroup (16 per wave)
 
-// Dynamic LDS: per wave ub[nv] and row0[nv + 1] (u16), then the decisions of the workgroup's tries.
-__global__ void __launch_bounds__(256) k_band_select(BandSelArgs a)
+// adds 1 (and `extra`) per lane to counters[key] (key < 0: none) with ONE atomic per distinct key of the wave; returns the lane's
+// rank among the lanes of its key plus the counter's old value (= its slot when the counter is a cursor)
+__device__ __forceinline__ uint32_t wave_key_add(uint32_t* counters, int key, int lane)
+{
+	uint32_t res = 0;
+	unsigned long long todo = __builtin_amdgcn_ballot_w64(key >= 0);
+	while (todo) {
+		const int leader = __ffsll((long long)todo) - 1;
+		const int k = __shfl(key, leader, 64);
+		const unsigned long long mk = __builtin_amdgcn_ballot_w64(key == k);
+		uint32_t base = 0;
+		if (lane == leader) base = atomicAdd(counters + k, (uint32_t)__popcll(mk));
+		base = (uint32_t)__shfl((int)base, leader, 64);
+		if (key == k) res = base + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull));
+		todo &= ~mk;
+	}
+	return res;
+}
+
+// Dynamic LDS: per wave ub[nv] and row0[nv + 1] (u16).
+__global__ void __launch_bounds__(256) k_band_decide(BandSelArgs a)
 {
 	extern __shared__ __align__(16) uint16_t sel_lds[];
-	__shared__ int d_cls[SEL_TRIES], d_q0[SEL_TRIES], d_theta[SEL_TRIES], d_slot[SEL_TRIES];
+	__shared__ int d_cls[SEL_TRIES], d_cols[SEL_TRIES];
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const int nv = 128 * a.ntiles;
 	uint16_t* ub = sel_lds + (size_t)wv * (2 * nv + 2);
@@ -87,7 +111,7 @@ __global__ void __launch_bounds__(256) k_band_select(BandSelArgs a)
 	const int w0 = blockIdx.x * SEL_TRIES;
 	for (int k = 0; k < SEL_TRIES / 4; k++) {
 		const int slot_k = wv * (SEL_TRIES / 4) + k, w = w0 + slot_k;
-		if (w >= a.n) { if (lane == 0) d_cls[slot_k] = -2; continue; }
+		if (w >= a.n) { if (lane == 0) { d_cls[slot_k] = -1; d_cols[slot_k] = 0; } continue; }
 		const int p = a.idx ? a.idx[w] : w;
 		const FwdProb pb = a.probs[p];
 		const int L = pb.len, unit = pb.stream_off;              // (the host passes the unit in the field the band path does not use)
@@ -161,44 +185,61 @@ __global__ void __launch_bounds__(256) k_band_select(BandSelArgs a)
 				if (theta <= T) { chosen = c; ch_q0 = q0; ch_theta = theta; }
 			}
 		}
-		if (lane == 0) { d_cls[slot_k] = chosen; d_q0[slot_k] = ch_q0; d_theta[slot_k] = ch_theta; }
-	}
-	__syncthreads();
-	// ---- one slot allocation per class for the whole workgroup
-	if (wv == 0) {
-		const int cls = d_cls[lane];
-		int nq = 0;
-		if (cls >= 0) { const int w = w0 + lane; const int p = a.idx ? a.idx[w] : w; nq = (a.probs[p].len + 2 + 3) / 4; }
-		int myslot = -1;
-		for (int c = 0; c < 3; c++) {
-			const unsigned long long mk = __builtin_amdgcn_ballot_w64(cls == c);
-			if (!mk) continue;
-			int cols = cls == c ? 4 * nq : 0;
-			for (int o = 32; o > 0; o >>= 1) cols += __shfl_xor(cols, o, 64);
-			uint32_t base = 0;
-			if (lane == 0) { base = atomicAdd(a.counts + c, (uint32_t)__popcll(mk)); atomicAdd(a.counts + 4 + c, (uint32_t)cols); }
-			base = (uint32_t)__shfl((int)base, 0, 64);
-			if (cls == c) myslot = (int)base + __popcll(mk & ((1ull << lane) - 1ull));
+		if (lane == 0) {
+			d_cls[slot_k] = chosen < 0 ? -1 : chosen * BAND_MAX_ZONES + ch_q0 / a.zs;
+			d_cols[slot_k] = chosen < 0 ? (umax >= 148 ? -1 : -2) : 4 * ((L + 2 + 3) / 4);
+			a.dec[w] = make_int4(chosen, ch_q0, ch_theta, 0);
 		}
-		d_slot[lane] = myslot;
 	}
 	__syncthreads();
-	// ---- list entries and column streams
-	const int voidw = BAND_VOID_BIT | (5 * a.nl * 7);
+	// ---- counters: tries per (class, zone), stream columns per class, and (debug) the tries left unbanded by reason
+	if (wv == 0) {
+		const int key = d_cls[lane], cols = d_cols[lane];
+		(void)wave_key_add(a.counts, key, lane);
+		for (int c = 0; c < 3; c++) {
+			int x = (key >= 0 && key / BAND_MAX_ZONES == c) ? cols : 0;
+			for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+			if (lane == 0 && x) atomicAdd(a.counts + BAND_COUNT_COLS + c, (uint32_t)x);
+		}
+		if (a.debug) (void)wave_key_add(a.counts, key < 0 && w0 + lane < a.n ? (cols == -1 ? BAND_COUNT_HOT : BAND_COUNT_NOBAND) : -1, lane);
+	}
+}
+
+// second half: slots inside the (class, zone) segments of the lists, list entries and column streams
+__global__ void __launch_bounds__(256) k_band_emit(BandSelArgs a)
+{
+	__shared__ int d_slot[SEL_TRIES], d_key[SEL_TRIES];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int w0 = blockIdx.x * SEL_TRIES;
+	if (wv == 0) {
+		const int w = w0 + lane;
+		int key = -1;
+		if (w < a.n) { const int4 d = a.dec[w]; if (d.x >= 0) key = d.x * BAND_MAX_ZONES + d.y / a.zs; }
+		d_key[lane] = key;
+		d_slot[lane] = (int)wave_key_add(a.cursors, key, lane);
+	}
+	__syncthreads();
 	for (int k = 0; k < SEL_TRIES / 4; k++) {
 		const int slot_k = wv * (SEL_TRIES / 4) + k, w = w0 + slot_k;
-		const int cls = d_cls[slot_k];
-		if (cls == -2) continue;
+		if (w >= a.n) continue;
 		const int p = a.idx ? a.idx[w] : w;
-		if (cls < 0 || (uint32_t)d_slot[slot_k] >= a.list_cap) { if (lane == 0) a.out[p].flags = 16; continue; }
+		const int key = d_key[slot_k];
+		if (key < 0 || (uint32_t)d_slot[slot_k] >= a.list_cap) { if (lane == 0) a.out[p].flags = 16; continue; }
+		const int4 d = a.dec[w];
+		const int cls = d.x, q0 = d.y;
 		const FwdProb pb = a.probs[p];
-		const int L = pb.len, nq = (L + 2 + 3) / 4, q0 = d_q0[slot_k];
+		const int L = pb.len, nq = (L + 2 + 3) / 4;
 		const uint32_t slot = (uint32_t)d_slot[slot_k];
 		if (lane == 0) {
-			BandTry bt; bt.prob = p; bt.r0 = 48 * q0; bt.theta_min = d_theta[slot_k]; bt.nq = nq;
+			BandTry bt; bt.prob = p; bt.r0 = 48 * q0; bt.theta_min = d.z; bt.nq = nq;
 			a.list[cls][slot] = bt;
 			a.out[p].flags = 8;
 		}
+		// LDS lanes per code of this class's launches, band start relative to the zone's first lane
+		const int G = 8 << cls;
+		const int lc = a.zs + G < a.nl ? a.zs + G : a.nl;
+		const int qrel = q0 - (q0 / a.zs) * a.zs;
+		const int voidw = BAND_VOID_BIT | (5 * lc * 7);
 		// two columns per lane and store: 64 lanes cover 128 columns per round
 		uint32_t* s2 = reinterpret_cast<uint32_t*>(a.slots[cls] + (size_t)slot * BAND_SLOT_COLS);
 		const int lead = 4 * nq - L;
@@ -211,7 +252,7 @@ __global__ void __launch_bounds__(256) k_band_select(BandSelArgs a)
 				if (pos >= lead) {
 					const int col = pos - lead;
 					int code = a.tcodes[pb.tbase + col]; if (code > 4) code = 4;
-					x = (code * a.nl + q0) * 7;
+					x = (code * lc + qrel) * 7;
 					if (col == L - 1) x |= BAND_LAST_BIT;
 				}
 				word |= (uint32_t)x << (16 * h);
@@ -221,20 +262,33 @@ __global__ void __launch_bounds__(256) k_band_select(BandSelArgs a)
 	}
 }
 
-hipError_t launch_band_select(const BandSelLaunch& L, hipStream_t st)
+static void band_sel_args(const BandSelLaunch& L, BandSelArgs& a)
+{
+	a.probs = L.probs; a.target = L.target; a.idx = L.idx; a.n = L.n; a.tstride = L.tstride; a.ublk = L.ublk; a.ublk_blocks = L.ublk_blocks;
+	a.m = L.m; a.seg16 = (L.m + 15) / 16; a.vs = systolic_vs(L.m); a.ntiles = a.vs / 8; a.nl = band_profile_lanes(L.m); a.zs = band_zone_stride(L.m);
+	a.prev_ub = L.prev_ub; a.prev = L.prev_ub ? L.prev : nullptr;
+	a.tcodes = L.tcodes; a.list_cap = L.list_cap; a.dec = L.dec; a.counts = L.counts; a.cursors = L.cursors; a.out = L.out; a.class_mask = L.class_mask; a.debug = L.debug;
+	for (int c = 0; c < 3; c++) { a.list[c] = L.list[c]; a.slots[c] = L.slots[c]; }
+}
+
+hipError_t launch_band_decide(const BandSelLaunch& L, hipStream_t st)
 {
 	if (L.n <= 0) return hipSuccess;
-	BandSelArgs a;
-	a.probs = L.probs; a.target = L.target; a.idx = L.idx; a.n = L.n; a.tstride = L.tstride; a.ublk = L.ublk; a.ublk_blocks = L.ublk_blocks;
-	a.m = L.m; a.seg16 = (L.m + 15) / 16; a.vs = systolic_vs(L.m); a.ntiles = a.vs / 8; a.nl = band_profile_lanes(L.m);
-	a.prev_ub = L.prev_ub; a.prev = L.prev_ub ? L.prev : nullptr;
-	a.tcodes = L.tcodes; a.list_cap = L.list_cap; a.counts = L.counts; a.out = L.out; a.class_mask = L.class_mask;
-	for (int c = 0; c < 3; c++) { a.list[c] = L.list[c]; a.slots[c] = L.slots[c]; }
+	BandSelArgs a; band_sel_args(L, a);
 	if (128 * a.ntiles > SEL_MAXV) return hipErrorInvalidValue;
-	hipError_t err = hipMemsetAsync(a.counts, 0, 8 * sizeof(uint32_t), st);
+	hipError_t err = hipMemsetAsync(a.counts, 0, BAND_COUNTS * sizeof(uint32_t), st);
 	if (err != hipSuccess) return err;
 	const size_t lds = (size_t)4 * (2 * 128 * a.ntiles + 2) * sizeof(uint16_t);
-	hipLaunchKernelGGL(k_band_select, dim3((unsigned)((L.n + SEL_TRIES - 1) / SEL_TRIES)), dim3(256), lds, st, a);
+	hipLaunchKernelGGL(k_band_decide, dim3((unsigned)((L.n + SEL_TRIES - 1) / SEL_TRIES)), dim3(256), lds, st, a);
+	return hipGetLastError();
+}
+
+// L.cursors must hold the first slot of every (class, zone) segment (the host derives them from the counts of launch_band_decide)
+hipError_t launch_band_emit(const BandSelLaunch& L, hipStream_t st)
+{
+	if (L.n <= 0) return hipSuccess;
+	BandSelArgs a; band_sel_args(L, a);
+	hipLaunchKernelGGL(k_band_emit, dim3((unsigned)((L.n + SEL_TRIES - 1) / SEL_TRIES)), dim3(256), 0, st, a);
 	return hipGetLastError();
 }
 
@@ -242,8 +296,10 @@ hipError_t launch_band_select(const BandSelLaunch& L, hipStream_t st)
 // k_align_band
 // ------------------------------------------------------------------------------------------------
 struct BandArgs {
-	const BandTry* list; const uint16_t* slots; int32_t n;
+	const BandTry* list; const uint16_t* slots;
+	const BandZoneTab* tab;              // per workgroup: its zone and its share of the zone's segment of the list
 	const uint8_t* qcodes; int32_t m, nl;
+	int32_t lc;                          // profile lanes per code held in LDS (the zone's lanes plus one band height)
 	FwdOut* out;
 };
 
@@ -272,7 +328,6 @@ __device__ __forceinline__ uint32_t gprev(uint32_t x, bool is_start)
 
 __device__ __forceinline__ int band_cell_score(const BandArgs& a, int t, int row)
 {
-	if (row >= 48 * a.nl) return BAND_NEG;
 	if (row >= 16 * ((a.m + 15) / 16)) return BAND_NEG;      // below the padded query: dead rows (never the column maximum)
 	if (row >= a.m) return 0;                                 // zero-score pad rows (Q3)
 	const int q = a.qcodes[row];
@@ -285,13 +340,14 @@ __global__ void __launch_bounds__(BAND_THREADS) __attribute__((amdgpu_waves_per_
 	constexpr int NG = 64 / G;                               // sub-pipelines per wave
 	constexpr int SC = BAND_SC;
 	extern __shared__ __align__(16) uint8_t lds[];
-	uint8_t* prof = lds;                                     // [5 codes][nl lanes][112] | void block [G][112]
-	const int code_stride = a.nl * BAND_LANE_STRIDE;
+	uint8_t* prof = lds;                                     // [5 codes][lc lanes][112] | void block [G][112]
+	const int code_stride = a.lc * BAND_LANE_STRIDE;
+	const BandZoneTab zt = a.tab[blockIdx.x];
 	uint4* fifo = reinterpret_cast<uint4*>(lds + 5 * code_stride + G * BAND_LANE_STRIDE);     // [wave][NG][G]
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	for (int idx = threadIdx.x; idx < 5 * a.nl * 48; idx += blockDim.x) {
-		const int r = idx % 48, l = (idx / 48) % a.nl, t = idx / (48 * a.nl);
-		*reinterpret_cast<int16_t*>(prof + t * code_stride + l * BAND_LANE_STRIDE + r * 2) = (int16_t)band_cell_score(a, t, 48 * l + r);
+	for (int idx = threadIdx.x; idx < 5 * a.lc * 48; idx += blockDim.x) {
+		const int r = idx % 48, l = (idx / 48) % a.lc, t = idx / (48 * a.lc);
+		*reinterpret_cast<int16_t*>(prof + t * code_stride + l * BAND_LANE_STRIDE + r * 2) = (int16_t)band_cell_score(a, t, 48 * (zt.zbase + l) + r);
 	}
 	for (int idx = threadIdx.x; idx < G * 56; idx += blockDim.x)
 		*reinterpret_cast<int16_t*>(prof + 5 * code_stride + idx * 2) = (int16_t)BAND_NEG;
@@ -304,17 +360,18 @@ __global__ void __launch_bounds__(BAND_THREADS) __attribute__((amdgpu_waves_per_
 	const uint8_t* pl = prof + j * BAND_LANE_STRIDE;
 	// row keys: (column maximum << 16) | (0xFFFF - row relative to the band's first row)
 	const int kbase_lo = 0xFFFF - (2 * j) * BAND_RPB - 31, kbase_hi = 0xFFFF - (2 * j + 1) * BAND_RPB - 31;
-	const uint32_t voidw = (uint32_t)(BAND_VOID_BIT | (5 * a.nl * 7));
+	const uint32_t voidw = (uint32_t)(BAND_VOID_BIT | (5 * a.lc * 7));
 	const uint2 void4 = make_uint2(voidw * 0x10001u, voidw * 0x10001u);
 
-	// ---- feeder (meaningful in the first lane of each sub-pipeline): windows are dealt out round robin
-	const int gstride = (int)gridDim.x * (BAND_THREADS / 64) * NG;
-	int f_idx = ((int)blockIdx.x * (BAND_THREADS / 64) + wv) * NG + grp;      // next window of this sub-pipeline
+	// ---- feeder (meaningful in the first lane of each sub-pipeline): the windows of the zone's list segment are dealt out round
+	//      robin over the sub-pipelines of the workgroups that serve the zone
+	const int gstride = zt.nwg * (BAND_THREADS / 64) * NG, f_end = zt.first + zt.count;
+	int f_idx = zt.first + (zt.wg * (BAND_THREADS / 64) + wv) * NG + grp;      // next window of this sub-pipeline
 	const uint2* f_slot = nullptr; int f_q = 0, f_nq = 0;                      // current window: stream, position, length (groups of 4 columns)
 	int n_start = 0;
 	uint2 feed_next = void4;
 	BandTry nbt; nbt.prob = -1; nbt.r0 = 0; nbt.theta_min = 0; nbt.nq = 0;
-	if (is_start && f_idx < a.n) nbt = a.list[f_idx];
+	if (is_start && f_idx < f_end) nbt = a.list[f_idx];
 
 	int H[BAND_RPB], E[BAND_RPB];
 #pragma unroll
@@ -331,13 +388,13 @@ __global__ void __launch_bounds__(BAND_THREADS) __attribute__((amdgpu_waves_per_
 			if (f_q >= f_nq) {
 				// the current window is fully issued: start the next one of this sub-pipeline (its descriptor was fetched when
 				// the current one started)
-				if (f_idx < a.n) {
+				if (f_idx < f_end) {
 					f_slot = reinterpret_cast<const uint2*>(a.slots + (size_t)f_idx * BAND_SLOT_COLS);
 					f_nq = nbt.nq; f_q = 0;
 					myfifo[n_start & (FIFO - 1)] = make_uint4((uint32_t)nbt.prob, (uint32_t)nbt.theta_min, (uint32_t)nbt.r0, 0u);
 					n_start++;
 					f_idx += gstride;
-					if (f_idx < a.n) nbt = a.list[f_idx];
+					if (f_idx < f_end) nbt = a.list[f_idx];
 				} else { f_slot = nullptr; f_nq = 0; f_q = 0; }
 			}
 			if (f_slot) { feed_next = f_slot[f_q]; f_q++; } else feed_next = void4;
@@ -421,9 +478,13 @@ __global__ void __launch_bounds__(BAND_THREADS) __attribute__((amdgpu_waves_per_
 }
 
 int band_profile_lanes(int m) { return (16 * ((m + 15) / 16) + 47) / 48; }
-size_t band_lds_bytes(int m, int G) { return (size_t)(5 * band_profile_lanes(m) + G) * BAND_LANE_STRIDE + (size_t)(BAND_THREADS / 64) * 64 * sizeof(uint4); }
-// classes (bit c: G = 8 << c) the band kernel runs for a query of m rows: the profile must fit the LDS budget and the band must
-// be at most 3/8 of the query's height (a band of half the height costs more than it saves: measured on H19, G = 32)
+// Zones: a query longer than 64 profile lanes (3 072 rows) does not stage its whole profile; a workgroup of the band kernel holds
+// the lanes of ONE zone (zs lanes plus one band height) and works on the tries whose band starts in that zone.
+int band_zone_stride(int m) { const int nl = band_profile_lanes(m); int zs = 64; while ((nl + zs - 1) / zs > BAND_MAX_ZONES) zs *= 2; return nl <= zs ? nl : zs; }
+static int band_lc(int m, int G) { const int nl = band_profile_lanes(m), zs = band_zone_stride(m); return zs + G < nl ? zs + G : nl; }
+size_t band_lds_bytes(int m, int G) { return (size_t)(5 * band_lc(m, G) + G) * BAND_LANE_STRIDE + (size_t)(BAND_THREADS / 64) * 64 * sizeof(uint4); }
+// classes (bit c: G = 8 << c) the band kernel runs for a query of m rows: the profile lanes of a zone must fit the LDS budget and the
+// band must be at most 3/8 of the query's height (a band of half the height costs more than it saves: measured on H19, G = 32)
 int band_classes(int m)
 {
 	if (!systolic_fits(m) || systolic_tiles(m) > 16) return 0;
@@ -431,41 +492,55 @@ int band_classes(int m)
 	const int nl = band_profile_lanes(m);
 	for (int c = 0; c < 3; c++) {
 		const int G = 8 << c;
-		if (8 * G <= 3 * nl && band_lds_bytes(m, G) <= 72 * 1024 && (5 * nl + G) * 7 < BAND_VOID_BIT) mask |= 1 << c;
+		if (8 * G <= 3 * nl && band_lds_bytes(m, G) <= 72 * 1024 && (5 * band_lc(m, G) + G) * 7 < BAND_VOID_BIT) mask |= 1 << c;
 	}
 	return mask;
 }
 
-template <int G>
-static hipError_t launch_band_t(const BandArgs& a, size_t lds, hipStream_t st)
+// Workgroups of one class's launch: every zone with tries gets a share of about 512 workgroups (two per CU) in proportion to its
+// tries, at least one and at most one per 3 windows of a sub-pipeline (a short list is spread thin: a launch lasts as long as its
+// longest sub-pipeline).  Returns the table the kernel reads (one entry per workgroup).
+std::vector<BandZoneTab> band_plan(int m, int cls, const uint32_t* zone_count, const uint32_t* zone_first)
 {
-	constexpr int NG = 64 / G;
-	// Two workgroups per CU fill the chip (512 of them); a long list gives every sub-pipeline about 24 windows or more (the fill
-	// of its 2 G virtual lanes is then amortised), a short one is spread thin instead (at least 3 windows per sub-pipeline): the
-	// launch is as long as its longest sub-pipeline.
-	constexpr int GPB = (BAND_THREADS / 64) * NG;         // sub-pipelines per workgroup
-	long per = ((long)a.n + 512L * GPB - 1) / (512L * GPB);
-	if (per < 3) per = 3;
-	long blocks = ((long)a.n + per * GPB - 1) / (per * GPB);
-	if (blocks > 512) blocks = 512;
-	if (blocks < 1) blocks = 1;
+	const int G = 8 << cls, gpb = (BAND_THREADS / 64) * (64 / G), zs = band_zone_stride(m);
+	const int nz = (band_profile_lanes(m) + zs - 1) / zs;
+	uint64_t total = 0;
+	for (int z = 0; z < nz; z++) total += zone_count[z];
+	std::vector<BandZoneTab> tab;
+	if (!total) return tab;
+	for (int z = 0; z < nz; z++) {
+		const uint32_t n = zone_count[z];
+		if (!n) continue;
+		long nwg = (long)((512.0 * n) / (double)total + 0.5);
+		const long cap = ((long)n + 3L * gpb - 1) / (3L * gpb);
+		if (nwg > cap) nwg = cap;
+		if (nwg < 1) nwg = 1;
+		for (long w = 0; w < nwg; w++) { BandZoneTab t; t.zbase = z * zs; t.first = (int32_t)zone_first[z]; t.count = (int32_t)n; t.wg = (int32_t)w; t.nwg = (int32_t)nwg; tab.push_back(t); }
+	}
+	return tab;
+}
+
+template <int G>
+static hipError_t launch_band_t(const BandArgs& a, int nwg, size_t lds, hipStream_t st)
+{
 	static bool attr_set = false;                   // (benign race: the call is idempotent)
 	if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_align_band<G>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024); attr_set = true; }
-	hipLaunchKernelGGL((k_align_band<G>), dim3((unsigned)blocks), dim3(BAND_THREADS), lds, st, a);
+	hipLaunchKernelGGL((k_align_band<G>), dim3((unsigned)nwg), dim3(BAND_THREADS), lds, st, a);
 	return hipGetLastError();
 }
 
 hipError_t launch_align_band(const BandLaunch& L, hipStream_t st)
 {
-	if (L.n <= 0) return hipSuccess;
+	if (L.nwg <= 0) return hipSuccess;
 	BandArgs a;
-	a.list = L.list; a.slots = L.slots; a.n = L.n; a.qcodes = L.qcodes; a.m = L.m; a.nl = band_profile_lanes(L.m); a.out = L.out;
+	a.list = L.list; a.slots = L.slots; a.tab = L.tab; a.qcodes = L.qcodes; a.m = L.m; a.nl = band_profile_lanes(L.m); a.out = L.out;
 	const int G = 8 << L.cls;
+	a.lc = band_lc(L.m, G);
 	const size_t lds = band_lds_bytes(L.m, G);
 	switch (L.cls) {
-	case 0: return launch_band_t<8>(a, lds, st);
-	case 1: return launch_band_t<16>(a, lds, st);
-	case 2: return launch_band_t<32>(a, lds, st);
+	case 0: return launch_band_t<8>(a, L.nwg, lds, st);
+	case 1: return launch_band_t<16>(a, L.nwg, lds, st);
+	case 2: return launch_band_t<32>(a, L.nwg, lds, st);
 	default: return hipErrorInvalidValue;
 	}
 }

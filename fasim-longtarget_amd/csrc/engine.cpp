@@ -127,7 +127,7 @@ struct fasim_engine {
 	int64_t kernel_launches[FASIM_KERNEL_FAMILIES] = { 0 };
 	// banded stage 3 (band.hip): block maxima left by the last main k_scan pass of this engine, lists and column streams of the
 	// tries selected per band class
-	DevBuf ublk, btarget, bidx, bcounts, blist[3], bslots[3], bprev, lane_ub, fzones, fubslot;
+	DevBuf ublk, btarget, bidx, bcounts, blist[3], bslots[3], bprev, lane_ub, fzones, fubslot, bdec, btab;
 	int ublk_units = 0, ublk_blocks = 0;         // units covered by `ublk` (0: none), blocks per (unit, tile)
 	const uint32_t* ub_view = nullptr;           // (as tc_view) the block maxima of the batch's owner during a stolen sub-task
 	int opt_band = -1;                           // option "band": 0 off, 1 on (-1 = default / environment FASIM_BAND)
@@ -938,7 +938,8 @@ int run_fwd_band(fasim_engine* E, const UnitBatch& B, const std::vector<WindowPr
 	for (int k = 0; k < n; k++) { probs[k].tbase = (int64_t)W[k].unit * B.tstride + W[k].t0; probs[k].len = W[k].len; probs[k].stream_off = W[k].unit; }      // (stream_off carries the unit here)
 	int rc = upload_async(E, E->fprobs, probs.data(), sizeof(FwdProb) * n); if (rc) return rc;
 	HIPOK(E->fout.ensure(sizeof(FwdOut) * n));
-	HIPOK(E->bcounts.ensure(64));
+	HIPOK(E->bcounts.ensure(sizeof(uint32_t) * (BAND_COUNTS + 3 * BAND_MAX_ZONES)));
+	HIPOK(E->bdec.ensure(sizeof(int4) * (size_t)n));
 	for (int c = 0; c < 3; c++) {
 		if (!((mask >> c) & 1)) continue;
 		HIPOK(E->blist[c].ensure(sizeof(BandTry) * (size_t)n));
@@ -965,28 +966,56 @@ int run_fwd_band(fasim_engine* E, const UnitBatch& B, const std::vector<WindowPr
 		S.probs = E->fprobs.as<FwdProb>(); S.target = E->btarget.as<int32_t>(); S.idx = pass ? E->bidx.as<int32_t>() : nullptr; S.n = np; S.tstride = B.tstride;
 		S.ublk = E->ub_view ? E->ub_view : E->ublk.as<uint32_t>(); S.ublk_blocks = E->ublk_blocks; S.m = E->m; S.tcodes = tcv(E);
 		for (int c = 0; c < 3; c++) { S.list[c] = E->blist[c].as<BandTry>(); S.slots[c] = E->bslots[c].as<uint16_t>(); }
-		S.list_cap = (uint32_t)n; S.counts = E->bcounts.as<uint32_t>(); S.out = E->fout.as<FwdOut>(); S.class_mask = mask;
+		S.list_cap = (uint32_t)n; S.counts = E->bcounts.as<uint32_t>(); S.cursors = E->bcounts.as<uint32_t>() + BAND_COUNTS; S.dec = E->bdec.as<int4>();
+		S.out = E->fout.as<FwdOut>(); S.class_mask = mask;
+		static const bool dbg = getenv("FASIM_BAND_DEBUG") != nullptr;
+		S.debug = dbg ? 1 : 0;
 		hipError_t he;
-		{ TimedScope ts(E, 9); he = launch_band_select(S, E->st); }
-		if (he != hipSuccess) return fail(E, FASIM_E_HIP, "band_select launch failed: %s", hipGetErrorString(he));
-		uint32_t counts[8] = { 0 };
+		{ TimedScope ts(E, 9); he = launch_band_decide(S, E->st); }
+		if (he != hipSuccess) return fail(E, FASIM_E_HIP, "band_decide launch failed: %s", hipGetErrorString(he));
+		uint32_t counts[BAND_COUNTS] = { 0 };
 		HIPOK(hipMemcpyAsync(counts, E->bcounts.p, sizeof counts, hipMemcpyDeviceToHost, E->st));
 		HIPOK(hipStreamSynchronize(E->st));       // (the host vectors uploaded above may go out of scope from here on)
-		if (counts[0] + counts[1] + counts[2]) {
+		// the (class, zone) segments of the lists, and the workgroups that will serve them
+		uint32_t first[3 * BAND_MAX_ZONES], per_class[3] = { 0, 0, 0 };
+		for (int c = 0; c < 3; c++) for (int z = 0; z < BAND_MAX_ZONES; z++) { first[c * BAND_MAX_ZONES + z] = per_class[c]; per_class[c] += counts[c * BAND_MAX_ZONES + z]; }
+		if (per_class[0] + per_class[1] + per_class[2]) {
+			std::vector<BandZoneTab> tabs[3]; std::vector<BandZoneTab> all;
+			size_t toff[3] = { 0, 0, 0 };
+			for (int c = 0; c < 3; c++) { if (per_class[c]) tabs[c] = band_plan(E->m, c, counts + c * BAND_MAX_ZONES, first + c * BAND_MAX_ZONES); toff[c] = all.size(); all.insert(all.end(), tabs[c].begin(), tabs[c].end()); }
+			HIPOK(hipMemcpyAsync(S.cursors, first, sizeof first, hipMemcpyHostToDevice, E->st));
+			rc = upload_async(E, E->btab, all.data(), sizeof(BandZoneTab) * all.size()); if (rc) return rc;
+			{ TimedScope ts(E, 9); he = launch_band_emit(S, E->st); }
+			if (he != hipSuccess) return fail(E, FASIM_E_HIP, "band_emit launch failed: %s", hipGetErrorString(he));
+			HIPOK(hipStreamSynchronize(E->st));       // (`first` and `all` are host stack / heap; st_heavy may be another stream)
 			GateScope gate(E);
 			for (int c = 0; c < 3; c++) {
-				if (!counts[c]) continue;
+				if (!per_class[c]) continue;
 				BandLaunch L;
-				L.list = E->blist[c].as<BandTry>(); L.slots = E->bslots[c].as<uint16_t>(); L.n = (int)counts[c]; L.cls = c;
+				L.list = E->blist[c].as<BandTry>(); L.slots = E->bslots[c].as<uint16_t>(); L.tab = E->btab.as<BandZoneTab>() + toff[c]; L.nwg = (int)tabs[c].size(); L.cls = c;
 				L.qcodes = E->q2.as<uint8_t>(); L.m = E->m; L.out = E->fout.as<FwdOut>();
 				{ TimedScope ts(E, 8, E->st_heavy); he = launch_align_band(L, E->st_heavy); }
 				if (he != hipSuccess) return fail(E, FASIM_E_HIP, "align_band launch failed: %s", hipGetErrorString(he));
-				if (st) { st->band_tries += counts[c]; st->band_cells += (int64_t)counts[4 + c] * 48 * (8 << c); st->cells_stage3 += (int64_t)counts[4 + c] * 48 * (8 << c); }
+				const int64_t cells = (int64_t)counts[BAND_COUNT_COLS + c] * 48 * (8 << c);
+				if (st) { st->band_tries += per_class[c]; st->band_cells += cells; st->cells_stage3 += cells; }
 			}
 			HIPOK(hipStreamSynchronize(E->st_heavy));
+		} else {
+			// nothing banded: every try of the pass is marked for the full-height kernel
+			HIPOK(hipMemcpyAsync(S.cursors, first, sizeof first, hipMemcpyHostToDevice, E->st));
+			{ TimedScope ts(E, 9); he = launch_band_emit(S, E->st); }
+			if (he != hipSuccess) return fail(E, FASIM_E_HIP, "band_emit launch failed: %s", hipGetErrorString(he));
+			HIPOK(hipStreamSynchronize(E->st));
 		}
 		HIPOK(hipMemcpyAsync(fo.data(), E->fout.p, sizeof(FwdOut) * n, hipMemcpyDeviceToHost, E->st));
 		HIPOK(hipStreamSynchronize(E->st));
+		if (dbg) {
+			long proven = 0, unproven = 0, withprev = 0;
+			for (int k = 0; k < n; k++) { if (!(fo[k].flags & 24)) proven++; else if (fo[k].flags & 8) unproven++; }
+			if (psrc) for (int k = 0; k < np; k++) if (psrc[k] >= 0) withprev++;
+			fprintf(stderr, "[band] pass %d: %d tries looked at (%ld with bounds of an earlier pass), classes %u / %u / %u, bound >= 148: %u, no band: %u; after the pass %ld of %d proven, %ld unproven\n",
+				pass, np, withprev, per_class[0], per_class[1], per_class[2], counts[BAND_COUNT_HOT], counts[BAND_COUNT_NOBAND], proven, n, unproven);
+		}
 	}
 	if (st) for (int k = 0; k < n; k++) if (!(fo[k].flags & 24)) st->band_proven++;
 	return FASIM_OK;
@@ -1309,7 +1338,7 @@ void fasim_engine_destroy(fasim_engine* e)
 		&e->unit_first, &e->hz_cols, &e->hz_plan, &e->hz_base, &e->hz_items, &e->snap, &e->hz_state, &e->hz_rows, &e->hz_chunk, &e->hz_src, &e->hz_zero,
 		&e->qsim, &e->sim_min, &e->sim_row, &e->sim_ev, &e->sim_cnt, &e->sim_nodes,
 		&e->ublk, &e->btarget, &e->bidx, &e->bcounts, &e->blist[0], &e->blist[1], &e->blist[2], &e->bslots[0], &e->bslots[1], &e->bslots[2],
-		&e->bprev, &e->lane_ub, &e->fzones, &e->fubslot };
+		&e->bprev, &e->lane_ub, &e->fzones, &e->fubslot, &e->bdec, &e->btab };
 	for (auto& t : e->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
 	for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
 	for (DevBuf* b : bufs) b->release();

@@ -1,6 +1,7 @@
 // Host-callable launchers of the gfx950 kernels (defined in kernels.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <vector>
 #include "device_types.h"
 
 namespace fasim {
@@ -111,18 +112,33 @@ hipError_t launch_finish_big(const uint8_t* tcodes, const uint8_t* qcodes, const
 // score reaches theta_min; nq = length of the try's column stream in groups of 4 columns
 struct BandTry { int32_t prob, r0, theta_min, nq; };
 constexpr int BAND_SLOT_COLS = 208;       // 16-bit stream words per try (window <= 200 columns + 2 void columns, rounded up to 4)
+constexpr int BAND_MAX_ZONES = 16;
+// counters of one selection pass: [class * BAND_MAX_ZONES + zone] tries, then stream columns per class, then (debug) the tries left
+// unbanded because a bound reaches 148 / because no band proves the target
+constexpr int BAND_COUNT_COLS = 3 * BAND_MAX_ZONES, BAND_COUNT_HOT = BAND_COUNT_COLS + 3, BAND_COUNT_NOBAND = BAND_COUNT_COLS + 4, BAND_COUNTS = 64;
 struct BandSelLaunch {
 	const FwdProb* probs; const int32_t* target; const int32_t* idx; int32_t n, tstride;
 	const uint32_t* ublk; int32_t ublk_blocks; int32_t m; const uint8_t* tcodes;
 	// tighter bounds from an earlier full-height pass of the same candidate (k_align_fwd's lane maxima): prev[k] = slot * 4 + zone
 	// (zone 1..3) or -1; NULL: none
 	const uint16_t* prev_ub = nullptr; const int32_t* prev = nullptr;
-	BandTry* list[3]; uint16_t* slots[3]; uint32_t list_cap; uint32_t* counts; FwdOut* out; int32_t class_mask;
+	BandTry* list[3]; uint16_t* slots[3]; uint32_t list_cap;
+	int4* dec;                // [n] decisions (decide -> emit)
+	uint32_t* counts;         // [BAND_COUNTS], zeroed and filled by launch_band_decide
+	uint32_t* cursors;        // [3 * BAND_MAX_ZONES] first slot of every (class, zone) segment, consumed by launch_band_emit
+	FwdOut* out; int32_t class_mask;
+	int32_t debug = 0;        // 1: count the tries left unbanded by reason
 };
-struct BandLaunch { const BandTry* list; const uint16_t* slots; int32_t n, cls; const uint8_t* qcodes; int32_t m; FwdOut* out; };
+// one workgroup of a band launch: profile lanes [zbase, zbase + lc) staged in LDS, tries list[first .. first + count) shared by
+// the `nwg` workgroups of the zone (this one is number `wg`)
+struct BandZoneTab { int32_t zbase, first, count, wg, nwg; };
+struct BandLaunch { const BandTry* list; const uint16_t* slots; const BandZoneTab* tab; int32_t nwg, cls; const uint8_t* qcodes; int32_t m; FwdOut* out; };
 int band_profile_lanes(int m);
+int band_zone_stride(int m);          // profile lanes per zone (== band_profile_lanes(m) for queries that need one zone)
 int band_classes(int m);              // bit c set: class c (sub-pipelines of 8 << c lanes = 384 << c rows) is available for this query
-hipError_t launch_band_select(const BandSelLaunch& L, hipStream_t st);
+std::vector<BandZoneTab> band_plan(int m, int cls, const uint32_t* zone_count, const uint32_t* zone_first);
+hipError_t launch_band_decide(const BandSelLaunch& L, hipStream_t st);
+hipError_t launch_band_emit(const BandSelLaunch& L, hipStream_t st);
 hipError_t launch_align_band(const BandLaunch& L, hipStream_t st);
 
 // ---- sim.hip: forward sweep of classic SIM (-F), one wave per unit ---------------------------------------
