@@ -360,7 +360,7 @@ def main():
             "kernel_launches": {KERNEL_NAMES[i]: int(agg["kernel_launches"][i]) for i in KERNEL_SHOWN},
             "counts": {k: int(agg[k]) for k in ("segments", "segments_skipped", "units", "candidates", "align_calls", "hazard_units", "rev_exact",
                                                 "exact_replays", "tries_skipped", "align_word_reruns", "stage2_overflow_units", "stage1_word_reruns",
-                                                "band_tries", "band_proven", "band_cells")},
+                                                "band_tries", "band_proven", "band_cells", "rev_bound_passes")},
             "per_unit": {"candidates": round(agg["candidates"] / max(1, agg["units"]), 2),
                          "hazard_units_pct": round(100.0 * agg["hazard_units"] / max(1, agg["units"]), 3),
                          "overflow_units_pct": round(100.0 * agg["stage2_overflow_units"] / max(1, agg["units"]), 3)},

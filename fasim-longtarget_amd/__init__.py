@@ -64,7 +64,7 @@ class ScanStats(C.Structure):
                 ("kernel_ms", C.c_double * 10), ("kernel_launches", C.c_int64 * 10), ("cells_stage1", C.c_int64),
                 ("cells_stage2", C.c_int64), ("cells_stage3", C.c_int64), ("hazard_units", C.c_int64), ("rev_exact", C.c_int64),
                 ("exact_replays", C.c_int64), ("tries_skipped", C.c_int64), ("band_tries", C.c_int64), ("band_proven", C.c_int64),
-                ("band_cells", C.c_int64)]
+                ("band_cells", C.c_int64), ("rev_bound_passes", C.c_int64)]
 
 
 class SimNode(C.Structure):

@@ -82,16 +82,18 @@ __global__ void k_build_stream(const uint8_t* __restrict__ tcodes, const FwdProb
 	if (p >= nprob) return;
 	const FwdProb pb = probs[p];
 	uint8_t* s = stream + pb.stream_off;
-	// zones[p] = lengths of the candidate's next three window tries (one byte each, 0 = none): they end in the same column
+	// zones != NULL: the REVERSED window (last column first) for the reverse pass; zones[p] = lengths of the candidate's next
+	// three window tries (one byte each, 0 = none).  They end in the window's last column, so in the reversed stream they are
+	// prefixes: the zone of a column = how many of them hold it
 	const uint32_t z = zones ? zones[p] : 0u;
-	const int z1 = pb.len - (int)(z & 0xffu), z2 = pb.len - (int)((z >> 8) & 0xffu), z3 = pb.len - (int)((z >> 16) & 0xffu);
+	const int z1 = (int)(z & 0xffu), z2 = (int)((z >> 8) & 0xffu), z3 = (int)((z >> 16) & 0xffu);
 	for (int c = threadIdx.x; c < pb.len + 2; c += blockDim.x) {
 		uint8_t v;
 		if (c < 2) v = CODE_VOID;
 		else {
 			const int col = c - 2;
-			v = tcodes[pb.tbase + col]; if (v >= 4) v = CODE_SN; if (col == pb.len - 1) v |= TAG_LAST;
-			if (z) v |= (uint8_t)((((z & 0xffu) && col >= z1) + (((z >> 8) & 0xffu) && col >= z2) + (((z >> 16) & 0xffu) && col >= z3)) << 5);
+			v = tcodes[pb.tbase + (zones ? pb.len - 1 - col : col)]; if (v >= 4) v = CODE_SN; if (col == pb.len - 1) v |= TAG_LAST;
+			if (zones) v |= (uint8_t)(((col < z1) + (col < z2) + (col < z3)) << 5);
 		}
 		s[c] = v;
 	}
@@ -116,8 +118,9 @@ struct FwdArgs {
 	FwdOut* out;
 	int32_t vs, tile, ntiles;      // query tiling as in scan.hip
 	uint4* boundary;               // [stream position]: {hbot | fbot<<16, fpo | hazard<<16, key, 0} between tiles
-	// bounds for the banded passes of the candidate's later tries (8-bit pass only): per window and zone z = 1..3 the maximum H
-	// of every virtual lane over the columns of zone >= z, written to lane_ub[(ub_slot[prob] * 3 + z - 1) * nv + virtual lane]
+	// reverse pass (plain variant only; lane_ub != NULL): the query is staged reversed and the stream holds reversed windows, so H
+	// of a cell = the best alignment that STARTS there.  Per window and zone z = 0..3 the maximum of every virtual lane over the
+	// columns of zone >= z goes to lane_ub[(ub_slot[prob] * 4 + z) * nv + virtual lane]; no FwdOut is written.
 	uint16_t* lane_ub; const int32_t* ub_slot; int32_t nv;
 };
 
@@ -136,7 +139,7 @@ __device__ __forceinline__ int fwd_cell_score(const FwdArgs& a, int t, int v, in
 	if (t == CODE_VOID || r >= rows_v) return AL_NEG;
 	const int row = row0v + r;
 	if (row >= a.m) return 0;                 // zero-score pad rows (Q3)
-	const int q = a.qcodes[row];
+	const int q = a.qcodes[a.lane_ub ? a.m - 1 - row : row];
 	return ((q == t && t < 4) ? 5 : -4) * sc;
 }
 
@@ -205,7 +208,7 @@ __global__ void __launch_bounds__(FWD_THREADS) __attribute__((amdgpu_waves_per_e
 		int chunk = CODE_VOID;
 		// pipe-end state (meaningful in lane 63)
 		int pidx = p0, cidx = 0, runmax = 0, end_ref = -1, end_read = 0, hzflag = 0, over = 0, wtaint = 0;
-		v2u zacc1 = (v2u){ 0, 0 }, zacc2 = (v2u){ 0, 0 }, zacc3 = (v2u){ 0, 0 }, wcnt = (v2u){ 0, 0 };      // zone maxima of my two virtual lanes; windows they have finished
+		v2u zacc0 = (v2u){ 0, 0 }, zacc1 = (v2u){ 0, 0 }, zacc2 = (v2u){ 0, 0 }, zacc3 = (v2u){ 0, 0 }, wcnt = (v2u){ 0, 0 };      // (reverse pass) zone maxima of my two virtual lanes; windows they have finished
 		const int nsteps = slen + 127;
 		for (int step = 0; step < nsteps; step++) {
 			if ((step & 63) == 0) {
@@ -289,12 +292,13 @@ __global__ void __launch_bounds__(FWD_THREADS) __attribute__((amdgpu_waves_per_e
 			const v2s lkey = __builtin_elementwise_max(__builtin_elementwise_max(lkx[0], lkx[1]), __builtin_elementwise_max(lkx[2], lkx[3]));
 			asm volatile("" :: "v"(a_i(lkey)));      // pin the reduction before the hazard branch (see scan.hip)
 			fbot = a_i(f);
-			if constexpr (TAINT) {
+			if constexpr (!TAINT) {
 				if (a.lane_ub) {
-					// my two columns' maxima (value = key >> 6) go into the running maxima of the zones that hold the column
+					// reverse pass: my two columns' maxima (value = key >> 5) go into the running maxima of the zones that hold the column
 					const v2u tcu = u_from(tc);
 					const v2u zz = (tcu >> (v2u){ 5, 5 }) & (v2u){ 3, 3 };
-					const v2u val = a_u(lkey) >> (v2u){ 6, 6 };
+					const v2u val = a_u(lkey) >> (v2u){ 5, 5 };
+					zacc0 = __builtin_elementwise_max(zacc0, val);
 					zacc1 = __builtin_elementwise_max(zacc1, val & ((v2u){ 0, 0 } - __builtin_elementwise_min(zz, (v2u){ 1, 1 })));
 					zacc2 = __builtin_elementwise_max(zacc2, val & ((v2u){ 0, 0 } - __builtin_elementwise_min(__builtin_elementwise_sub_sat(zz, (v2u){ 1, 1 }), (v2u){ 1, 1 })));
 					zacc3 = __builtin_elementwise_max(zacc3, val & ((v2u){ 0, 0 } - __builtin_elementwise_sub_sat(zz, (v2u){ 2, 2 })));
@@ -305,13 +309,13 @@ __global__ void __launch_bounds__(FWD_THREADS) __attribute__((amdgpu_waves_per_e
 							if (lastb[h]) {
 								const int slot = a.ub_slot[p0 + (int)wcnt[h]];
 								if (slot >= 0) {
-									uint16_t* o = a.lane_ub + (size_t)slot * 3 * a.nv + 128 * a.tile + 2 * lane + h;
-									o[0] = zacc1[h]; o[a.nv] = zacc2[h]; o[2 * (size_t)a.nv] = zacc3[h];
+									uint16_t* o = a.lane_ub + (size_t)slot * 4 * a.nv + 128 * a.tile + 2 * lane + h;
+									o[0] = zacc0[h]; o[a.nv] = zacc1[h]; o[2 * (size_t)a.nv] = zacc2[h]; o[3 * (size_t)a.nv] = zacc3[h];
 								}
 							}
 						}
 						const v2u keep = lastb - (v2u){ 1, 1 };
-						zacc1 &= keep; zacc2 &= keep; zacc3 &= keep;
+						zacc0 &= keep; zacc1 &= keep; zacc2 &= keep; zacc3 &= keep;
 						wcnt += lastb;
 					}
 				}
@@ -401,7 +405,7 @@ __global__ void __launch_bounds__(FWD_THREADS) __attribute__((amdgpu_waves_per_e
 					}
 					cidx++;
 					if (tag & TAG_LAST) {
-						if (lane == 0) {
+						if (lane == 0 && !(!TAINT && a.lane_ub)) {
 							FwdOut o;
 							o.score = runmax; o.ref_end = end_ref; o.read_end = end_read < a.m - 1 ? end_read : a.m - 1;
 							o.flags = hzflag | wtaint; o.ref_begin = 0; o.read_begin = 0;
@@ -436,7 +440,7 @@ hipError_t launch_align_fwd(const FwdLaunch& L, hipStream_t st)
 	a.stream = L.stream; a.probs = L.probs; a.task_first = L.task_first; a.ntask = L.ntask; a.counter = L.counter;
 	a.qcodes = L.qcodes; a.m = L.m; a.m_pad = 16 * ((L.m + 15) / 16); a.seg_len16 = (L.m + 15) / 16; a.out = L.out;
 	a.vs = systolic_vs(L.m); a.ntiles = a.vs / 8; a.boundary = L.boundary;
-	a.lane_ub = L.word ? nullptr : L.lane_ub; a.ub_slot = L.ub_slot; a.nv = 128 * a.ntiles;
+	a.lane_ub = L.word ? L.lane_ub : nullptr; a.ub_slot = L.ub_slot; a.nv = 128 * a.ntiles;
 	if (a.ntiles > 1 && !a.boundary) return hipErrorInvalidValue;
 	const int rp = (a.seg_len16 + a.vs - 1) / a.vs;
 	for (int t = 0; t < a.ntiles; t++) {

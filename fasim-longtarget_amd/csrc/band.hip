@@ -120,7 +120,16 @@ __global__ void __launch_bounds__(256) k_band_decide(BandSelArgs a)
 		// ---- upper bounds per virtual lane of k_scan: the blocks of steps [t0 + v, pe + v] (v = lane index inside the tile)
 		int umax = 0;
 		const int pv = a.prev ? a.prev[w] : -1;
-		const uint16_t* PU = pv >= 0 ? a.prev_ub + ((size_t)(pv >> 2) * 3 + ((pv & 3) - 1)) * nv : nullptr;
+		// start-based bounds of the reverse pass: lane maxima of the REVERSED problem (lane v' holds reversed rows r0s[v'] ..)
+		const uint16_t* PU = pv >= 0 ? a.prev_ub + (size_t)pv * nv : nullptr;
+		if (PU) {
+			for (int i = 0; i < a.ntiles; i++) {
+				const uint32_t y = *reinterpret_cast<const uint32_t*>(PU + 128 * i + 2 * lane);
+				const int p0 = (int)(y & 0xffffu), p1 = (int)(y >> 16);
+				ub[128 * i + 2 * lane] = (uint16_t)p0; ub[128 * i + 2 * lane + 1] = (uint16_t)p1;
+				umax = p0 > umax ? p0 : umax; umax = p1 > umax ? p1 : umax;
+			}
+		} else
 		for (int i = 0; i < a.ntiles; i++) {
 			const uint32_t* U = a.ublk + (((size_t)unit * a.ntiles + i) * a.ublk_blocks) * 64 + lane;
 			const int b0 = (t0 + 2 * lane) / SCAN_UBLK_STEPS;
@@ -138,12 +147,6 @@ __global__ void __launch_bounds__(256) k_band_decide(BandSelArgs a)
 			}
 			if (u0 > 5 * L) u0 = 5 * L;
 			if (u1 > 5 * L) u1 = 5 * L;
-			if (PU) {
-				// H of this try <= H of the earlier, longer window of the same candidate, column by column
-				const uint32_t y = *reinterpret_cast<const uint32_t*>(PU + 128 * i + 2 * lane);
-				const int p0 = (int)(y & 0xffffu), p1 = (int)(y >> 16);
-				u0 = p0 < u0 ? p0 : u0; u1 = p1 < u1 ? p1 : u1;
-			}
 			ub[128 * i + 2 * lane] = (uint16_t)u0; ub[128 * i + 2 * lane + 1] = (uint16_t)u1;
 			umax = u0 > umax ? u0 : umax; umax = u1 > umax ? u1 : umax;
 		}
@@ -153,7 +156,45 @@ __global__ void __launch_bounds__(256) k_band_decide(BandSelArgs a)
 		int T = a.target[w];
 		if (T > umax) T = umax;
 		// a bound of 148 or more: the reference's signed lazy-F exit (Q2) or its 8-bit overflow could show -> full-height kernel
-		if (umax < 148 && T >= 1) {
+		if (PU && umax < 148 && umax >= 1) {
+			// Start-based bounds: ub[v'] = the best score of an alignment of THIS window that starts in reversed lane v', so umax is
+			// the window's exact score.  Every cell with H >= theta ends an alignment that starts in a lane with ub >= theta and
+			// reaches at most rmax(theta) - 1 rows further down: the band has to hold those lanes and that many rows below them.
+			T = umax;
+			const int mpad = 16 * a.seg16;
+			int tf = 1 << 30, bf = -1;
+			for (int v = lane; v < nv; v += 64) if ((int)ub[v] >= T) {
+				const int lo = r0s[v], hi = r0s[v + 1];
+				const int ot = a.m - hi > 0 ? a.m - hi : 0, ob = a.m - 1 - lo > 0 ? a.m - 1 - lo : 0;      // original rows of the lane
+				tf = ot < tf ? ot : tf; bf = ob > bf ? ob : bf;
+			}
+			for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(tf, o, 64), z = __shfl_xor(bf, o, 64); tf = y < tf ? y : tf; bf = z > bf ? z : bf; }
+			const int gaps = 5 * L - T - 12;
+			const int rmax = gaps >= 4 ? L + gaps / 4 : L;
+			for (int c = 0; c < 3 && chosen < 0; c++) {
+				const int G = 8 << c;
+				if (!((a.class_mask >> c) & 1) || G > a.nl) continue;
+				int q0 = tf / 48; if (q0 > a.nl - G) q0 = a.nl - G;
+				const int r0 = 48 * q0, r1 = r0 + 48 * G;
+				if (r1 < mpad && r1 < bf + rmax) continue;                 // does not hold the rows below the last start lane
+				int theta = 1;
+				for (int v = lane; v < nv; v += 64) {
+					const int lo = r0s[v], hi = r0s[v + 1], u = ub[v];
+					const int ot = a.m - hi > 0 ? a.m - hi : 0, ob = a.m - 1 - lo > 0 ? a.m - 1 - lo : 0;
+					int tau;
+					if (ot < r0) tau = u + 1;                             // starts above the band: must not reach theta
+					else if (r1 >= mpad) tau = 1;
+					else {
+						const int D = r1 - ob;                             // rows from the lane's last row to the end of the band
+						const int ts = D >= L ? 9 * L - 4 * D - 15 : 5 * L + 1;
+						tau = u + 1 < ts ? u + 1 : ts;
+					}
+					theta = tau > theta ? tau : theta;
+				}
+				for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(theta, o, 64); theta = y > theta ? y : theta; }
+				if (theta <= T) { chosen = c; ch_q0 = q0; ch_theta = theta; }
+			}
+		} else if (!PU && umax < 148 && T >= 1) {
 			int vf = 1 << 30, vl = -1;
 			for (int v = lane; v < nv; v += 64) if ((int)ub[v] >= T) { vf = v < vf ? v : vf; vl = v > vl ? v : vl; }
 			for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(vf, o, 64), z = __shfl_xor(vl, o, 64); vf = y < vf ? y : vf; vl = z > vl ? z : vl; }

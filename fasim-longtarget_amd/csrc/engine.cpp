@@ -698,8 +698,8 @@ static inline const uint8_t* tcv(const fasim_engine* E) { return E->tc_view ? E-
 int run_finish(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, const std::vector<FwdOut>& fo,
 	std::vector<AlignResult>& out, std::vector<uint32_t>& cigars, std::vector<char>& status);
 bool align_v2_fits(const fasim_engine* E, const std::vector<WindowProb>& W);
-// what the 8-bit full-height forward pass leaves for the banded passes of the candidates' later tries (band.hip): per window
-// the lengths of the next three tries (zone tags of the stream) and the slot of the candidate in E->lane_ub (-1: none)
+// input of the reverse pass (band.hip, align.hip): per window the lengths of the candidate's next three tries (zone tags of the
+// reversed stream) and the candidate's slot in E->lane_ub
 struct FwdZones { std::vector<uint32_t> zones; std::vector<int32_t> slot; };
 int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, std::vector<FwdOut>& fo, bool word, const FwdZones* Z = nullptr);
 
@@ -871,7 +871,9 @@ int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& 
 	tasks.push_back(n);
 	double tp = now_s();
 	int rc = upload_async(E, E->fprobs, probs.data(), sizeof(FwdProb) * n); if (rc) return rc;      // (both vectors outlive the
-	const bool emit = Z && !word && E->lane_ub.p && (int)Z->zones.size() == n && (int)Z->slot.size() == n;
+	// Z: the REVERSE pass (plain kernel, reversed query and windows): leaves lane maxima per zone in E->lane_ub and no FwdOut
+	const bool emit = Z != nullptr;
+	if (emit && (!word || !E->lane_ub.p || (int)Z->zones.size() != n || (int)Z->slot.size() != n)) return fail(E, FASIM_E_ARG, "reverse pass: bad arguments");
 	if (emit) {
 		rc = upload_async(E, E->fzones, Z->zones.data(), sizeof(uint32_t) * n); if (rc) return rc;
 		rc = upload_async(E, E->fubslot, Z->slot.data(), sizeof(int32_t) * n); if (rc) return rc;
@@ -897,6 +899,7 @@ int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& 
 	HIPOK(hipStreamSynchronize(E->st_heavy));
 	gate.release();
 	g_prof.add(2, "run_fwd kernel wait", now_s() - tp);
+	if (emit) return FASIM_OK;
 	tp = now_s();
 	HIPOK(hipMemcpyAsync(fo.data(), E->fout.p, sizeof(FwdOut) * n, hipMemcpyDeviceToHost, E->st));
 	HIPOK(hipStreamSynchronize(E->st));
@@ -908,9 +911,9 @@ int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& 
 // kernel, which then repeats the whole alignment with its 16-bit kernels (sswNew.cpp:1473-1477, no overflow rule,
 // unsigned-safe compare) -> second pass with the plain systolic kernel for those windows (flags = 4).  A window
 // whose winning cell is tainted (flags & 1) is not trusted either way: the caller replays it exactly.
-int run_fwd_both(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, std::vector<FwdOut>& fo, int64_t* word_reruns, const FwdZones* Z = nullptr)
+int run_fwd_both(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, std::vector<FwdOut>& fo, int64_t* word_reruns)
 {
-	int rc = run_fwd(E, B, W, fo, false, Z); if (rc) return rc;
+	int rc = run_fwd(E, B, W, fo, false); if (rc) return rc;
 	std::vector<int> ov;
 	for (size_t i = 0; i < fo.size(); i++) if (!(fo[i].flags & 1) && fo[i].score >= 255 - BIAS) ov.push_back((int)i);
 	if (ov.empty()) return FASIM_OK;
@@ -954,7 +957,8 @@ int run_fwd_band(fasim_engine* E, const UnitBatch& B, const std::vector<WindowPr
 		const int32_t* psrc = have_prev ? prev->data() : nullptr;
 		if (pass == 1) {
 			idx.clear(); tgt2.clear();
-			for (int k = 0; k < n; k++) if (fo[k].flags == 8 && fo[k].score > 0) { idx.push_back(k); tgt2.push_back(fo[k].score); if (have_prev) prev2.push_back((*prev)[k]); }
+			// (a try with start-based bounds was given its exact score as the target: a second band would be the same one)
+			for (int k = 0; k < n; k++) if (fo[k].flags == 8 && fo[k].score > 0 && !(have_prev && (*prev)[k] >= 0)) { idx.push_back(k); tgt2.push_back(fo[k].score); if (have_prev) prev2.push_back(-1); }
 			np = (int)idx.size(); tsrc = tgt2.data(); if (have_prev) psrc = prev2.data();
 			if (!np) break;
 			rc = upload_async(E, E->bidx, idx.data(), sizeof(int32_t) * np); if (rc) return rc;
@@ -1021,31 +1025,51 @@ int run_fwd_band(fasim_engine* E, const UnitBatch& B, const std::vector<WindowPr
 	return FASIM_OK;
 }
 
-// forward pass of a round of tries: banded where the block maxima of k_scan prove a band, full height otherwise
-// prev (optional): per try slot * 4 + zone of the bounds an earlier full-height pass of the candidate left, or -1;
-// Z (optional): zones / slots for the bounds this round's full-height pass leaves; went_full[k] = 1 where try k took that pass
+// Forward pass of a round of tries.
+//   1. band pass: a try whose candidate has start-based bounds from a reverse pass (ru[k] = slot * 4 + zone) gets the band those
+//      prove (its exact score is known); at a candidate's first try the block maxima of k_scan bound the window instead and the
+//      target is the candidate's own score (an accepted try reaches it); target 0 = no attempt.
+//   2. reverse pass (plain full-height kernel on the reversed problem) for the unproven tries without such bounds: leaves the
+//      bounds of this try (zone 0) and of the candidate's later tries (zones 1-3) in E->lane_ub; got_ru[k] = 1.
+//   3. band pass of those tries with the new bounds.
+//   4. whatever is still unproven (scores that can meet the reference's Q2 / overflow behaviour, start lanes too far apart for a
+//      band) takes the full-height forward passes (8-bit with taint tracking, 16-bit where the maximum reaches 251).
 bool band_ready(const fasim_engine* E, const UnitBatch& B) { return band_mask(E) != 0 && (E->ub_view || E->ublk_units >= B.nunit) && E->ublk_blocks > 0; }
 int run_fwd_smart(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, const std::vector<int32_t>& target,
-	const std::vector<int32_t>* prev, const FwdZones* Z, std::vector<FwdOut>& fo, std::vector<char>* went_full, fasim_scan_stats& st)
+	const std::vector<int32_t>* ru, const FwdZones* Z, std::vector<FwdOut>& fo, std::vector<char>* got_ru, fasim_scan_stats& st)
 {
-	if (went_full) went_full->assign(W.size(), 0);
+	if (got_ru) got_ru->assign(W.size(), 0);
 	if (!band_ready(E, B)) {
 		for (const WindowProb& w : W) st.cells_stage3 += (int64_t)E->m * w.len;
 		return run_fwd_both(E, B, W, fo, &st.align_word_reruns);
 	}
-	int rc = run_fwd_band(E, B, W, target, prev, fo, &st); if (rc) return rc;
+	int rc = run_fwd_band(E, B, W, target, ru, fo, &st); if (rc) return rc;
 	std::vector<int> rest;
 	for (size_t k = 0; k < fo.size(); k++) if (fo[k].flags & 24) rest.push_back((int)k);
 	if (rest.empty()) return FASIM_OK;
-	std::vector<WindowProb> W3(rest.size()); std::vector<FwdOut> f3;
-	FwdZones Z3;
-	for (size_t r = 0; r < rest.size(); r++) {
-		W3[r] = W[rest[r]]; st.cells_stage3 += (int64_t)E->m * W3[r].len;
-		if (Z) { Z3.zones.push_back(Z->zones[rest[r]]); Z3.slot.push_back(Z->slot[rest[r]]); }
-		if (went_full) (*went_full)[rest[r]] = 1;
+	if (Z && ru && E->lane_ub.p) {
+		std::vector<int> R;
+		for (int k : rest) if ((*ru)[(size_t)k] < 0) R.push_back(k);
+		if (!R.empty()) {
+			std::vector<WindowProb> WR(R.size()); FwdZones ZR; std::vector<int32_t> tR(R.size(), 1 << 30), ruR(R.size());
+			ZR.zones.resize(R.size()); ZR.slot.resize(R.size());
+			for (size_t r = 0; r < R.size(); r++) {
+				WR[r] = W[(size_t)R[r]]; ZR.zones[r] = Z->zones[(size_t)R[r]]; ZR.slot[r] = Z->slot[(size_t)R[r]]; ruR[r] = Z->slot[(size_t)R[r]] * 4;
+				st.cells_stage3 += (int64_t)E->m * WR[r].len; st.rev_bound_passes++;
+			}
+			std::vector<FwdOut> dummy, fR;
+			rc = run_fwd(E, B, WR, dummy, true, &ZR); if (rc) return rc;
+			rc = run_fwd_band(E, B, WR, tR, &ruR, fR, &st); if (rc) return rc;
+			for (size_t r = 0; r < R.size(); r++) { fo[(size_t)R[r]] = fR[r]; if (got_ru) (*got_ru)[(size_t)R[r]] = 1; }
+			rest.clear();
+			for (size_t k = 0; k < fo.size(); k++) if (fo[k].flags & 24) rest.push_back((int)k);
+			if (rest.empty()) return FASIM_OK;
+		}
 	}
-	rc = run_fwd_both(E, B, W3, f3, &st.align_word_reruns, Z ? &Z3 : nullptr); if (rc) return rc;
-	for (size_t r = 0; r < rest.size(); r++) fo[rest[r]] = f3[r];
+	std::vector<WindowProb> W3(rest.size()); std::vector<FwdOut> f3;
+	for (size_t r = 0; r < rest.size(); r++) { W3[r] = W[(size_t)rest[r]]; st.cells_stage3 += (int64_t)E->m * W3[r].len; }
+	rc = run_fwd_both(E, B, W3, f3, &st.align_word_reruns); if (rc) return rc;
+	for (size_t r = 0; r < rest.size(); r++) fo[(size_t)rest[r]] = f3[r];
 	return FASIM_OK;
 }
 
@@ -1903,7 +1927,7 @@ int stage3_range(fasim_engine* E, BatchCtx& C, int ua, int ub, fasim_scan_stats&
 		//      the reference's layout-dependent behaviour, or whose traceback fails in the reference (NULL ->
 		//      score 0 -> the loop would have continued), are replayed try by try on the stripe-faithful path.
 		t0 = now_s();
-		struct CandState { int unit; Cand c; AlignResult al, best; FwdOut fsel, fbest; int cut, bestcut; char done, flag, exact, ub_it; };
+		struct CandState { int unit; Cand c; AlignResult al, best; FwdOut fsel, fbest; int cut, bestcut; char done, flag, exact, ru_it; };
 		std::vector<uint32_t> cigars;
 		std::vector<CandState> cs;
 		{
@@ -1918,7 +1942,7 @@ int stage3_range(fasim_engine* E, BatchCtx& C, int ua, int ub, fasim_scan_stats&
 				for (int u = u0; u < u1; u++) {
 					pick_candidates(hits.data() + hoff[u], hcnt[u], tmp);
 					for (const Cand& c : tmp) { CandState x; memset(&x.fsel, 0, sizeof x.fsel); memset(&x.fbest, 0, sizeof x.fbest);
-						x.unit = u; x.c = c; x.done = 0; x.cut = 0; x.bestcut = 0; x.flag = 0; x.exact = 0; x.ub_it = -1; part[ti].push_back(x); }
+						x.unit = u; x.c = c; x.done = 0; x.cut = 0; x.bestcut = 0; x.flag = 0; x.exact = 0; x.ru_it = -1; part[ti].push_back(x); }
 				}
 			};
 			if (nt == 1) work(0);
@@ -1931,10 +1955,10 @@ int stage3_range(fasim_engine* E, BatchCtx& C, int ua, int ub, fasim_scan_stats&
 		st.candidates += (int64_t)cs.size();
 		bool v2 = true;
 		{ std::vector<WindowProb> probe(1, WindowProb{ 0, 0, 1 }); v2 = align_v2_fits(E, probe); }
-		// lane maxima left by the full-height passes (bounds for the banded passes of the candidates' later tries): [candidate][3][lanes]
-		static const bool zone_bounds = [] { const char* e = getenv("FASIM_BAND_ZONES"); return e ? atoi(e) != 0 : true; }();
-		const bool zb = v2 && zone_bounds && band_ready(E, B) && !cs.empty() &&
-			E->lane_ub.ensure((size_t)cs.size() * 3 * 128 * systolic_tiles(E->m) * sizeof(uint16_t)) == hipSuccess;
+		// lane maxima left by the reverse passes (start-based bounds of a candidate's tries): [candidate][4 zones][lanes]
+		static const bool rev_bounds = [] { const char* e = getenv("FASIM_BAND_REV"); return e ? atoi(e) != 0 : true; }();
+		const bool zb = v2 && rev_bounds && band_ready(E, B) && !cs.empty() &&
+			E->lane_ub.ensure((size_t)cs.size() * 4 * 128 * systolic_tiles(E->m) * sizeof(uint16_t)) == hipSuccess;
 		if (v2 && !zb) { (void)hipGetLastError(); E->lane_ub.release(); }
 		if (v2) {
 			for (int it = 0; it < 4; it++) {
@@ -1949,25 +1973,28 @@ int stage3_range(fasim_engine* E, BatchCtx& C, int ua, int ub, fasim_scan_stats&
 				}
 				if (W.empty()) break;
 				st.align_calls += (int64_t)W.size();
-				// what the try is expected to score: the candidate's own score at the first try (an accepted try reaches it), a
-				// fraction of the previous try's score afterwards (the windows shrink)
+				// Band targets.  A candidate that has been through a reverse pass has start-based bounds for all of its tries (its
+				// exact score is then known to the selection kernel); otherwise the first try aims at the candidate's own score (an
+				// accepted try reaches it), and a later try goes straight to the reverse pass, or, without reverse passes
+				// (FASIM_BAND_REV=0), aims at a fraction of the previous try's score.
 				static const int rho = [] { const char* e = getenv("FASIM_BAND_RHO"); const int v = e ? atoi(e) : 85; return v < 10 ? 10 : (v > 100 ? 100 : v); }();
-				std::vector<int32_t> target(W.size()), prev(zb ? W.size() : 0);
+				std::vector<int32_t> target(W.size()), ru(zb ? W.size() : 0);
 				FwdZones Z;
 				if (zb) { Z.zones.resize(W.size()); Z.slot.resize(W.size()); }
 				for (size_t i = 0; i < who.size(); i++) {
 					const CandState& x = cs[who[i]];
-					target[i] = it == 0 ? x.c.score : std::max(1, x.fsel.score * rho / 100);
+					target[i] = it == 0 ? x.c.score : (zb ? 0 : std::max(1, x.fsel.score * rho / 100));
 					if (zb) {
-						prev[i] = x.ub_it >= 0 ? who[i] * 4 + (it - x.ub_it) : -1;
+						ru[i] = x.ru_it >= 0 ? who[i] * 4 + (it - x.ru_it) : -1;
+						if (ru[i] >= 0) target[i] = 1 << 30;
 						uint32_t z = 0;
 						for (int j = 1; j <= 3 && it + j < 4; j++) { int cut; if (window_for_try(it + j, x.c.score, x.c.pos, &cut) && cut <= 255) z |= (uint32_t)cut << (8 * (j - 1)); }
 						Z.zones[i] = z; Z.slot[i] = who[i];
 					}
 				}
-				std::vector<FwdOut> fo; std::vector<char> went_full;
-				rc = run_fwd_smart(E, B, W, target, zb ? &prev : nullptr, zb ? &Z : nullptr, fo, &went_full, st); if (rc) return rc;
-				if (zb) for (size_t i = 0; i < who.size(); i++) if (went_full[i]) cs[who[i]].ub_it = (char)it;
+				std::vector<FwdOut> fo; std::vector<char> got_ru;
+				rc = run_fwd_smart(E, B, W, target, zb ? &ru : nullptr, zb ? &Z : nullptr, fo, &got_ru, st); if (rc) return rc;
+				if (zb) for (size_t i = 0; i < who.size(); i++) if (got_ru[i]) cs[who[i]].ru_it = (char)it;
 				std::vector<int> fwd_score(fo.size());
 				for (size_t i = 0; i < fo.size(); i++) fwd_score[i] = fo[i].score;
 				{
@@ -2229,7 +2256,7 @@ static void add_stats(fasim_scan_stats& st, const fasim_scan_stats& x)
 	st.t_stage2_s += x.t_stage2_s; st.t_stage3_s += x.t_stage3_s; st.t_host_s += x.t_host_s; st.cells_stage1 += x.cells_stage1;
 	st.cells_stage2 += x.cells_stage2; st.cells_stage3 += x.cells_stage3; st.hazard_units += x.hazard_units; st.rev_exact += x.rev_exact;
 	st.exact_replays += x.exact_replays; st.tries_skipped += x.tries_skipped;
-	st.band_tries += x.band_tries; st.band_proven += x.band_proven; st.band_cells += x.band_cells;
+	st.band_tries += x.band_tries; st.band_proven += x.band_proven; st.band_cells += x.band_cells; st.rev_bound_passes += x.rev_bound_passes;
 	for (int k = 0; k < FASIM_KERNEL_FAMILIES; k++) { st.kernel_ms[k] += x.kernel_ms[k]; st.kernel_launches[k] += x.kernel_launches[k]; }
 }
 

@@ -94,10 +94,12 @@ struct FwdLaunch {
 	const uint8_t* qcodes; int32_t m; FwdOut* out;
 	uint4* boundary;      // [stream position] hand-over between query tiles; needed when systolic_tiles(m) > 1
 	int32_t word;         // 1: the reference's 16-bit pass (no overflow rule, no Q2): plain variant without taint tracking
-	// (8-bit pass) per-lane maxima over the zones of the stream for the banded passes of later tries; NULL: not wanted
+	// reverse pass (word == 1, lane_ub != NULL): reversed query against reversed windows; leaves per window (slot ub_slot[k], -1:
+	// none) and zone 0..3 the per-lane maxima [slot][4][128 * tiles] and writes no FwdOut
 	uint16_t* lane_ub = nullptr; const int32_t* ub_slot = nullptr;
 };
-// zones: NULL, or per window the lengths of the candidate's next three tries (bytes 0..2; 0 = none) -> zone tags in the stream
+// zones: NULL, or (reverse pass) per window the lengths of the candidate's next three tries (bytes 0..2; 0 = none): the stream then
+// holds the REVERSED window with the zone of every column in bits 5-6
 hipError_t launch_build_stream(const uint8_t* tcodes, const FwdProb* probs, int32_t nprob, uint8_t* stream, const uint32_t* zones, hipStream_t st);
 hipError_t launch_align_fwd(const FwdLaunch& L, hipStream_t st);     // hipErrorInvalidValue: query too long
 hipError_t launch_finish(const uint8_t* tcodes, const uint8_t* qcodes, const FwdProb* probs, const FwdOut* fwd, const int32_t* order,
@@ -119,8 +121,8 @@ constexpr int BAND_COUNT_COLS = 3 * BAND_MAX_ZONES, BAND_COUNT_HOT = BAND_COUNT_
 struct BandSelLaunch {
 	const FwdProb* probs; const int32_t* target; const int32_t* idx; int32_t n, tstride;
 	const uint32_t* ublk; int32_t ublk_blocks; int32_t m; const uint8_t* tcodes;
-	// tighter bounds from an earlier full-height pass of the same candidate (k_align_fwd's lane maxima): prev[k] = slot * 4 + zone
-	// (zone 1..3) or -1; NULL: none
+	// start-based bounds from the reverse pass of the candidate (k_align_fwd's lane maxima over the reversed problem):
+	// prev[k] = slot * 4 + zone (zone 0..3) or -1 (then the block maxima of k_scan bound the try); NULL: none
 	const uint16_t* prev_ub = nullptr; const int32_t* prev = nullptr;
 	BandTry* list[3]; uint16_t* slots[3]; uint32_t list_cap;
 	int4* dec;                // [n] decisions (decide -> emit)

@@ -170,6 +170,7 @@ typedef struct fasim_scan_stats {
 	int64_t band_tries;                 /* forward passes run on a row band (k_align_band), second attempts included */
 	int64_t band_proven;                /* window tries whose band result was proven to be the full-height result */
 	int64_t band_cells;                 /* DP cells executed by k_align_band (part of cells_stage3) */
+	int64_t rev_bound_passes;           /* window tries that took the full-height reverse pass (bounds for the band passes) */
 } fasim_scan_stats;
 
 struct fasim_result {
