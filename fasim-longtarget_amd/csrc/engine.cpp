@@ -1650,7 +1650,9 @@ int fasim_align_batch(fasim_engine* E, const char* windows, const int64_t* offse
 	for (int i = 0; i < nprob; i++) {
 		out[i].sw_score = res[i].sw_score; out[i].ref_begin = res[i].ref_begin; out[i].ref_end = res[i].ref_end;
 		out[i].query_begin = res[i].query_begin; out[i].query_end = res[i].query_end;
-		out[i].cigar_len = std::min(res[i].cigar_len, 256);
+		// (the device tracebacks hold at most 62 runs and fail loudly beyond that; never hand back a truncated CIGAR)
+		if (res[i].cigar_len > 256) return fail(E, FASIM_E_UNSUPPORTED, "alignment %d has %d CIGAR runs; fasim_alignment holds 256", i, res[i].cigar_len);
+		out[i].cigar_len = res[i].cigar_len;
 		if (out[i].cigar_len) memcpy(out[i].cigar, cigars.data() + res[i].cigar_off, sizeof(uint32_t) * out[i].cigar_len);
 		if (res[i].failed) { out[i].sw_score = 0; out[i].cigar_len = -1; }     // the reference returns NULL here
 	}

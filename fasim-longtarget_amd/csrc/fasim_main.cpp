@@ -32,6 +32,7 @@
 #include <iostream>
 #include <deque>
 #include <mutex>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>
@@ -131,10 +132,14 @@ static std::vector<int> parse_devices(const char* s)
 	return v;
 }
 
-static void write_file(const std::string& path, const char* text, int64_t len)
+// returns 0 when every byte reached the file (a missing -O directory or a full disk must not end in "finished normally")
+static int write_file(const std::string& path, const char* text, int64_t len)
 {
 	std::ofstream of(path.c_str(), std::ios::trunc);
-	of.write(text, (std::streamsize)len);
+	if (of) of.write(text, (std::streamsize)len);
+	of.close();
+	if (!of) { fprintf(stderr, "fasim: cannot write %s\n", path.c_str()); return 1; }
+	return 0;
 }
 
 struct Timers { double parse = 0, scan = 0, tail = 0, write = 0, tail_wait = 0; };
@@ -148,12 +153,12 @@ static int write_outputs(const fasim_result* res, const std::string& stem, const
 	if (fasim_tail_outputs(res->recs, res->count, res->pool, res->pool_len, chr.c_str(), start, dna_len, lnc_name.c_str(), &p, flags,
 		&text[0], &len[0], &text[1], &len[1], &text[2], &len[2]) != FASIM_OK) { fprintf(stderr, "fasim: %s\n", fasim_last_error(nullptr)); return 1; }
 	tm.tail += now_s() - t0; t0 = now_s();
-	write_file(stem + "-TFOsorted", text[0], len[0]);
+	int bad = write_file(stem + "-TFOsorted", text[0], len[0]);
 	for (int level = 1; level <= 2; level++)     // print_cluster x2 (:832-836): <prefix>-TFOclass<level>-<ds>-<lg> (:706)
-		write_file(stem + "-TFOclass" + std::to_string(level) + "-" + std::to_string(p.cDistance) + "-" + std::to_string(p.cLength), text[level], len[level]);
+		bad |= write_file(stem + "-TFOclass" + std::to_string(level) + "-" + std::to_string(p.cDistance) + "-" + std::to_string(p.cLength), text[level], len[level]);
 	for (char* t : text) fasim_free(t);
 	tm.write += now_s() - t0;
-	return 0;
+	return bad;
 }
 
 // The host tail of record i (clustering, text, file writes) runs on its own thread while the devices already scan record
@@ -285,6 +290,7 @@ int main(int argc, char* const* argv)
 	size_t nrec = 0;
 	int64_t total_nt = 0;
 	std::deque<std::thread> pending;
+	std::set<std::string> stems_seen;
 	if (accumulate) {
 		// B1: tmpDNA is never cleared, so record k holds records 1..k; all triplexes go into ONE list that is printed with
 		// the first record's species / chr / start / length (main(), Fasim-LongTarget.cpp:133-166)
@@ -331,7 +337,11 @@ int main(int argc, char* const* argv)
 			}
 			t0 = now_s();
 			std::vector<fasim_result*> res;
-			if (scan_record(engines, rnas, rec.seq, p, res)) return 1;
+			if (scan_record(engines, rnas, rec.seq, p, res)) {
+				// the tails of earlier records still run on their threads: a joinable std::thread must not be destroyed
+				for (std::thread& t : pending) t.join();
+				return 1;
+			}
 			tm.scan += now_s() - t0;
 			total_nt += (int64_t)rec.seq.size();
 			for (size_t q = 0; q < rnas.size(); q++) {
@@ -342,6 +352,7 @@ int main(int argc, char* const* argv)
 						(long long)s.candidates, (long long)s.align_calls, (long long)res[q]->count);
 				}
 				const std::string stem = outdir + "/" + rec.species + "-" + rnas[q].name + "-" + base + (all_records ? "." + rec.chr : std::string());
+				if (!stems_seen.insert(stem).second) fprintf(stderr, "fasim: warning: %s-TFOsorted is written twice (two lncRNAs or records of the same name): the later one wins\n", stem.c_str());
 				// tail + write on a background thread: the next record is parsed and scanned meanwhile
 				while (pending.size() >= 4) { pending.front().join(); pending.pop_front(); }
 				fasim_result* r = res[q];
