@@ -297,7 +297,8 @@ __global__ void __launch_bounds__(FWD_THREADS) __attribute__((amdgpu_waves_per_e
 					// reverse pass: my two columns' maxima (value = key >> 5) go into the running maxima of the zones that hold the column
 					const v2u tcu = u_from(tc);
 					const v2u zz = (tcu >> (v2u){ 5, 5 }) & (v2u){ 3, 3 };
-					const v2u val = a_u(lkey) >> (v2u){ 5, 5 };
+					// (not the void columns: in the first one H still shows the E values the previous window left behind)
+					const v2u val = (a_u(lkey) >> (v2u){ 5, 5 }) & ~isvoid;
 					zacc0 = __builtin_elementwise_max(zacc0, val);
 					zacc1 = __builtin_elementwise_max(zacc1, val & ((v2u){ 0, 0 } - __builtin_elementwise_min(zz, (v2u){ 1, 1 })));
 					zacc2 = __builtin_elementwise_max(zacc2, val & ((v2u){ 0, 0 } - __builtin_elementwise_min(__builtin_elementwise_sub_sat(zz, (v2u){ 1, 1 }), (v2u){ 1, 1 })));

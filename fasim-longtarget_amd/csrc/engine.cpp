@@ -865,7 +865,8 @@ int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& 
 		off += W[k].len + 2;
 	}
 	if (off > 0x7fff0000ll) return fail(E, FASIM_E_UNSUPPORTED, "window stream of one round exceeds 2 GiB; lower FASIM_SEG_BATCH");
-	const int per_task = std::max(8, std::min(64, n / 3072));
+	static const int dbg_per_task = [] { const char* e = getenv("FASIM_DEBUG_PER_TASK"); return e ? atoi(e) : 0; }();
+	const int per_task = dbg_per_task > 0 ? dbg_per_task : std::max(8, std::min(64, n / 3072));
 	std::vector<int32_t> tasks;
 	for (int k = 0; k < n; k += per_task) tasks.push_back(k);
 	tasks.push_back(n);
@@ -1069,6 +1070,16 @@ int run_fwd_smart(fasim_engine* E, const UnitBatch& B, const std::vector<WindowP
 	std::vector<WindowProb> W3(rest.size()); std::vector<FwdOut> f3;
 	for (size_t r = 0; r < rest.size(); r++) { W3[r] = W[(size_t)rest[r]]; st.cells_stage3 += (int64_t)E->m * W3[r].len; }
 	rc = run_fwd_both(E, B, W3, f3, &st.align_word_reruns); if (rc) return rc;
+	if (getenv("FASIM_BAND_DEBUG")) {
+		int shown = 0;
+		for (size_t r = 0; r < rest.size() && shown < 12; r++) {
+			const FwdOut& b = fo[(size_t)rest[r]];
+			if (b.flags != 8) continue;
+			fprintf(stderr, "[band] unproven: unit %d t0 %d len %d band(score %d ref_end %d read_end %d) full(score %d ref_end %d read_end %d flags %d)\n",
+				W3[r].unit, W3[r].t0, W3[r].len, b.score, b.ref_end, b.read_end, f3[r].score, f3[r].ref_end, f3[r].read_end, f3[r].flags);
+			shown++;
+		}
+	}
 	for (size_t r = 0; r < rest.size(); r++) fo[(size_t)rest[r]] = f3[r];
 	return FASIM_OK;
 }
