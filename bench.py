@@ -61,6 +61,7 @@ KERNEL_NAMES = ["k_scan (fused stage 1+2)", "k_striped<PRE|MAX1> (stage 1/2 haza
                 "k_striped<ALIGN|REV> (stage 3 exact replays)", "k_finish/k_banded (global scratch)", "k_sim_forward (-F only)",
                 "k_align_band (stage 3 forward on row bands)", "k_band_select"]
 KERNEL_SHOWN = [0, 1, 2, 8, 9, 3, 4, 5, 6]
+PMC_FILE = "r03_pmc_traffic.json"      # HBM counters of the current build (tools/pmc_traffic.py)
 # packed VALU instructions per DP cell of the variants that are launched by default:
 #   k_scan<RP>: perm, add, 3 x max, 3 x sat-sub, 2 x max = 10 per row pair = 5.0 per cell
 #   k_align_fwd<RP,TAINT> and k_align_band<G>: the same + the row-key OR = 11 per row pair = 5.5 per cell
@@ -313,10 +314,20 @@ def main():
                 per_item = iso["cells_stage3"] / m / calls + 2 + 16 + 24
                 alt = {}
             alg = per_item * items / launches_k
+            # measured HBM bytes per launch: bytes per item from the committed counter passes (two separate rocprofv3 --pmc runs folded
+            # by tools/pmc_traffic.py; FETCH doubled for gfx950 as the guide prescribes) x the items of one launch
+            traffic, tnote = None, "no counter file under profiles/"
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
+                per = pmc["k_scan" if idx == 0 else "k_align_fwd"]["hbm_bytes_per_item"]
+                traffic = int(per * items / launches_k)
+                tnote = (f"profiles/{PMC_FILE}: {per:.0f} B per {'unit' if idx == 0 else 'window try'} (FETCH_SIZE x 2 + WRITE_SIZE of separate "
+                         "rocprofv3 --pmc passes, tools/pmc_traffic.py) x the items of one launch of this run")
+            except (OSError, KeyError, ValueError):
+                pass
             d = {"bound": "hbm", "kernel": KERNEL_NAMES[idx], "achieved": round(alg / (avg * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS,
-                 "unit": "GB/s", "frac": round(alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
-                 "traffic_note": "HBM bytes from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE are collected in separate profiled runs "
-                                 "(tools/pmc_traffic.py) and kept under profiles/; nothing is read from there at bench time",
+                 "unit": "GB/s", "frac": round(alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": traffic,
+                 "traffic_note": tnote,
                  "avg_launch_ms": round(avg, 3), "launches": int(launches_k), "algorithmic_bytes_per_launch": int(alg),
                  "items_per_launch": int(items / launches_k), "source": "isolated pass: one batch in flight, exclusive HIP-event durations",
                  "note": "integer DP is VALU-bound by construction (SURVEY 8(d)); see valu"}

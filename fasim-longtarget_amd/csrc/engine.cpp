@@ -77,7 +77,6 @@ struct ProfScope { int i; const char* nm; double t0; ProfScope(int i_, const cha
 struct fasim_engine {
 	int device = 0;
 	hipStream_t st = nullptr;
-	hipStream_t st_heavy = nullptr;   // stream of k_scan / k_align_fwd; == st unless FASIM_LIGHT_CUS reserves CUs for the other kernels
 	std::string err;
 	std::string rna;
 	int m = 0;
@@ -100,23 +99,18 @@ struct fasim_engine {
 	int host_threads_total = 1;
 	int host_threads_share_total = 1;            // (workers) the scan's total, for the share of a worker near the end of a scan
 	bool host_threads_explicit = false;          // FASIM_HOST_THREADS / option host_threads given: -F keeps to it too
-	std::thread reaper;                          // frees the host lists of the previous scan in the background
 	std::atomic<int>* active_workers = nullptr;  // (set for the duration of a scan) workers that still have batches: the host threads of
 	                                             // those that have run out go to the bursts of the others
 	int sim_threads = 1;                         // -F: host threads of this worker for the finish half (all cores shared by the batches in flight)
 	int opt_workers = 0, opt_seg_batch = 0;      // fasim_set_option overrides (0 = default / environment)
 	int opt_taper = -1, opt_gate = -1;           // (-1 = default / environment)
 	int hz_chunks = -1, hz_snap = -1, hz_target = 0, hz_hot_w = 0;   // chunked hazard re-run: on/off, snapshots on/off (-1 = default / environment), chunk cost target, hot-column weight (0 = default)
-	int opt_tail_split = 0, opt_tail_items = -1; // cooperative tail: sub-tasks per batch (0 = default 4), batches at the end whose stage 3 is shared (-1 = default: none)
 	bool query_acgt = true;       // query holds only A,C,G,T: stage-1 and stage-2 scoring coincide on N-free segments
 	bool scan_v1 = false;         // FASIM_SCAN_V1=1: force the stripe-faithful kernels for stages 1 and 2
 	int host_threads = 1;
 	// resident DNA record (fasim_load_dna)
 	std::string dna_host;
 	DevBuf dna_res;
-	// stage 3 reads target codes through this view: normally the engine's own `tcodes`, during a stolen sub-task (cooperative
-	// tail of a scan) the resident codes of the batch's owner
-	const uint8_t* tc_view = nullptr;
 	// streaming ingest (fasim_scan with a host buffer): pinned staging buffer of this worker's current batch slice
 	void* pin_dna = nullptr; size_t pin_cap = 0;
 	// HIP-event timing of kernel launches on `st`
@@ -129,7 +123,6 @@ struct fasim_engine {
 	// tries selected per band class
 	DevBuf ublk, btarget, bidx, bcounts, blist[3], bslots[3], bprev, lane_ub, fzones, fubslot, bdec, btab;
 	int ublk_units = 0, ublk_blocks = 0;         // units covered by `ublk` (0: none), blocks per (unit, tile)
-	const uint32_t* ub_view = nullptr;           // (as tc_view) the block maxima of the batch's owner during a stolen sub-task
 	int opt_band = -1;                           // option "band": 0 off, 1 on (-1 = default / environment FASIM_BAND)
 };
 
@@ -337,11 +330,15 @@ static int usable_cores()
 
 // Banded stage 3 (band.hip): classes usable for the current query; 0 = off (FASIM_BAND=0 / option band = 0, stripe-faithful
 // modes, queries the band kernel does not hold)
-static int band_mask(const fasim_engine* E)
+// option band / FASIM_BAND: 0 off, 1 on (default), 2 = bands from k_scan's block maxima only, no reverse passes (for measurements)
+static int band_mode(const fasim_engine* E)
 {
 	static const int env = [] { const char* e = getenv("FASIM_BAND"); return e ? atoi(e) : 1; }();
-	const int on = E->opt_band >= 0 ? E->opt_band : env;
-	if (!on || E->align_v1 || E->scan_v1) return 0;
+	return E->opt_band >= 0 ? E->opt_band : env;
+}
+static int band_mask(const fasim_engine* E)
+{
+	if (!band_mode(E) || E->align_v1 || E->scan_v1) return 0;
 	return band_classes(E->m);
 }
 
@@ -349,7 +346,10 @@ static int band_mask(const fasim_engine* E)
 // runs every hazard unit from column 0 instead of from the main pass's pipeline snapshots (both for measurements)
 // (options hazard_chunks / hazard_snapshots override the environment)
 static bool hazard_chunks_enabled(const fasim_engine* E) { static const bool v = [] { const char* e = getenv("FASIM_HAZARD_CHUNKS"); return e ? atoi(e) != 0 : true; }(); return E->hz_chunks >= 0 ? E->hz_chunks != 0 : v; }
-static bool hazard_snapshots_enabled(const fasim_engine* E) { static const bool v = [] { const char* e = getenv("FASIM_HAZARD_SNAP"); return e ? atoi(e) != 0 : true; }(); return E->hz_snap >= 0 ? E->hz_snap != 0 : v; }
+// Snapshots are OFF by default since round 3: they cost 67 KB of HBM writes per unit (2.3 x the algorithmic traffic of k_scan, 1.4 GB
+// per batch in flight) for the 0.8 % of the units that become hazard units, and buy 7 ms of a batch's latency that ten batches in flight
+// hide anyway (2.18 vs 2.21 s per 50 Mb step, inside the run-to-run noise: profiles/r03_ab_snapshots.txt).
+static bool hazard_snapshots_enabled(const fasim_engine* E) { static const bool v = [] { const char* e = getenv("FASIM_HAZARD_SNAP"); return e ? atoi(e) != 0 : false; }(); return E->hz_snap >= 0 ? E->hz_snap != 0 : v; }
 
 // Stripe-faithful re-run of the hazard units (Q2), cut into column chunks that run in PARALLEL (kernels.hip, "chunked hazard
 // re-run"; scan.hip, DUMP variant).
@@ -374,12 +374,11 @@ int run_hazard_chunked(fasim_engine* E, const UnitBatch& B, const std::vector<in
 	const int nh = (int)hz.size();
 	const int rows_total = 16 * ((E->m + 15) / 16);
 	const bool dbg = getenv("FASIM_DEBUG_HAZARD") != nullptr;
-	static const int env_target = [] { const char* e = getenv("FASIM_HAZARD_CHUNK_COLS"); const int v = e ? atoi(e) : 200; return v < 64 ? 64 : v; }();
+	const int env_target = 200;
 	const int target = E->hz_target > 0 ? E->hz_target : env_target;
-	static const int hot_thr = [] { const char* e = getenv("FASIM_HAZARD_HOT_THR"); return e ? atoi(e) : 144; }();
-	static const int env_hot_w = [] { const char* e = getenv("FASIM_HAZARD_HOT_W"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 32 ? 32 : v); }();
+	const int hot_thr = 144, env_hot_w = 2;
 	const int hot_w = E->hz_hot_w > 0 ? E->hz_hot_w : env_hot_w;
-	static const bool spread = [] { const char* e = getenv("FASIM_HAZARD_SPREAD"); return e ? atoi(e) != 0 : false; }();      // (measured: no gain alone, and 84 KB of LDS cannot start beside four k_scan workgroups)
+	const bool spread = false;
 	auto now = [] { return std::chrono::steady_clock::now(); };
 	auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
 	const auto t_begin = now();
@@ -539,7 +538,7 @@ int run_scan_v2(fasim_engine* E, const UnitBatch& B, const std::vector<char>& un
 	L.tcodes = E->tcodes.as<uint8_t>(); L.unit_len = E->unit_len.as<int32_t>(); L.tstride = B.tstride;
 	L.counter = E->counter.as<uint32_t>(); L.m = E->m; L.colmax16 = E->colmax16.as<uint16_t>();
 	L.boundary = nullptr; L.unit_hz = nullptr;
-	{ const char* c = getenv("FASIM_Q2_COARSE"); L.coarse = (c && atoi(c) > 0) ? 1 : 0; }
+	L.coarse = 0;
 	if (systolic_fits(E->m) && systolic_tiles(E->m) > 1) {
 		HIPOK(E->boundary.ensure((size_t)nu * B.tstride * sizeof(uint2)));
 		L.boundary = E->boundary.as<uint2>();
@@ -550,11 +549,9 @@ int run_scan_v2(fasim_engine* E, const UnitBatch& B, const std::vector<char>& un
 		// alphabet differs (Q4), so the exact stage-1 maximum needs its own pass
 		rc = upload(E, E->unit_ids, sep.data(), sizeof(int32_t) * sep.size()); if (rc) return rc;
 		L.unit_ids = E->unit_ids.as<int32_t>(); L.nwork = (int)sep.size(); L.qcodes = E->q1.as<uint8_t>(); fill_scores(L.score, true);
-		if (E->st_heavy != E->st) HIPOK(hipStreamSynchronize(E->st));
-		{ TimedScope ts(E, 0, E->st_heavy); he = launch_scan(L, E->st_heavy); }
+		{ TimedScope ts(E, 0, E->st); he = launch_scan(L, E->st); }
 		if (he == hipErrorInvalidValue) return 1;
 		if (he != hipSuccess) return fail(E, FASIM_E_HIP, "scan (stage-1 pass) launch failed: %s", hipGetErrorString(he));
-		if (E->st_heavy != E->st) HIPOK(hipStreamSynchronize(E->st_heavy));
 		he = launch_max16(E->colmax16.as<uint16_t>(), E->unit_ids.as<int32_t>(), (int)sep.size(), E->unit_len.as<int32_t>(),
 			B.tstride, E->stage1_in.as<int32_t>(), E->st);
 		if (he != hipSuccess) return fail(E, FASIM_E_HIP, "max16 launch failed: %s", hipGetErrorString(he));
@@ -588,13 +585,12 @@ int run_scan_v2(fasim_engine* E, const UnitBatch& B, const std::vector<char>& un
 			L.ublk = E->ublk.as<uint32_t>(); L.ublk_blocks = nb; E->ublk_units = nu; E->ublk_blocks = nb;
 		} else (void)hipGetLastError();
 	}
-	if (E->st_heavy != E->st) HIPOK(hipStreamSynchronize(E->st));      // k_encode and the memset above ran on the other stream
 	{
 		GateScope gate(E);
-		{ TimedScope ts(E, 0, E->st_heavy); he = launch_scan(L, E->st_heavy); }
+		{ TimedScope ts(E, 0, E->st); he = launch_scan(L, E->st); }
 		if (he == hipErrorInvalidValue) return 1;
 		if (he != hipSuccess) return fail(E, FASIM_E_HIP, "scan launch failed: %s", hipGetErrorString(he));
-		HIPOK(hipStreamSynchronize(E->st_heavy));
+		HIPOK(hipStreamSynchronize(E->st));
 	}
 
 	HIPOK(E->hit_off.ensure(sizeof(int32_t) * nu)); HIPOK(E->hit_cnt.ensure(sizeof(int32_t) * nu));
@@ -682,18 +678,11 @@ int run_scan_v2(fasim_engine* E, const UnitBatch& B, const std::vector<char>& un
 		out.hits.insert(out.hits.end(), hits2.begin(), hits2.end());
 		for (int u : hz) { out.hit_off[u] = (int32_t)(base + off2[u]); out.hit_cnt[u] = cnt2[u]; }
 	}
-	if (getenv("FASIM_DEBUG_UNITS")) {
-		for (int u = 0; u < nu; u++) {
-			uint64_t h = 1469598103934665603ULL;
-			for (int k = 0; k < out.hit_cnt[u]; k++) { h ^= out.hits[(size_t)out.hit_off[u] + k]; h *= 1099511628211ULL; }
-			fprintf(stderr, "[unit] %d s1=%d thr=%d hits=%d flags=%d h=%016llx\n", u, out.stage1[u], out.thr[u], out.hit_cnt[u], out.flags[u], (unsigned long long)h);
-		}
-	}
 	return FASIM_OK;
 }
 
 struct WindowProb { int unit, t0, len; };
-static inline const uint8_t* tcv(const fasim_engine* E) { return E->tc_view ? E->tc_view : E->tcodes.as<uint8_t>(); }
+static inline const uint8_t* tcv(const fasim_engine* E) { return E->tcodes.as<uint8_t>(); }
 
 int run_finish(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, const std::vector<FwdOut>& fo,
 	std::vector<AlignResult>& out, std::vector<uint32_t>& cigars, std::vector<char>& status);
@@ -865,8 +854,7 @@ int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& 
 		off += W[k].len + 2;
 	}
 	if (off > 0x7fff0000ll) return fail(E, FASIM_E_UNSUPPORTED, "window stream of one round exceeds 2 GiB; lower FASIM_SEG_BATCH");
-	static const int dbg_per_task = [] { const char* e = getenv("FASIM_DEBUG_PER_TASK"); return e ? atoi(e) : 0; }();
-	const int per_task = dbg_per_task > 0 ? dbg_per_task : std::max(8, std::min(64, n / 3072));
+	const int per_task = std::max(8, std::min(64, n / 3072));
 	std::vector<int32_t> tasks;
 	for (int k = 0; k < n; k += per_task) tasks.push_back(k);
 	tasks.push_back(n);
@@ -884,8 +872,7 @@ int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& 
 	HIPOK(E->fstream.ensure((size_t)off + 256));
 	HIPOK(E->fout.ensure(sizeof(FwdOut) * n));
 	GateScope gate(E);
-	if (E->st_heavy != E->st) HIPOK(hipStreamSynchronize(E->st));
-	hipError_t he = launch_build_stream(tcv(E), E->fprobs.as<FwdProb>(), n, E->fstream.as<uint8_t>(), emit ? E->fzones.as<uint32_t>() : nullptr, E->st_heavy);
+	hipError_t he = launch_build_stream(tcv(E), E->fprobs.as<FwdProb>(), n, E->fstream.as<uint8_t>(), emit ? E->fzones.as<uint32_t>() : nullptr, E->st);
 	if (he != hipSuccess) return fail(E, FASIM_E_HIP, "build_stream launch failed: %s", hipGetErrorString(he));
 	FwdLaunch L;
 	L.stream = E->fstream.as<uint8_t>(); L.probs = E->fprobs.as<FwdProb>(); L.task_first = E->ftasks.as<int32_t>();
@@ -894,10 +881,10 @@ int run_fwd(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& 
 	if (emit) { L.lane_ub = E->lane_ub.as<uint16_t>(); L.ub_slot = E->fubslot.as<int32_t>(); }
 	L.boundary = nullptr;
 	if (systolic_tiles(E->m) > 1) { HIPOK(E->fboundary.ensure(((size_t)off + 256) * sizeof(uint4))); L.boundary = E->fboundary.as<uint4>(); }
-	{ TimedScope ts(E, 2, E->st_heavy); he = launch_align_fwd(L, E->st_heavy); }
+	{ TimedScope ts(E, 2, E->st); he = launch_align_fwd(L, E->st); }
 	if (he != hipSuccess) return fail(E, FASIM_E_HIP, "align_fwd launch failed: %s", hipGetErrorString(he));
 	tp = now_s();
-	HIPOK(hipStreamSynchronize(E->st_heavy));
+	HIPOK(hipStreamSynchronize(E->st));
 	gate.release();
 	g_prof.add(2, "run_fwd kernel wait", now_s() - tp);
 	if (emit) return FASIM_OK;
@@ -949,7 +936,7 @@ int run_fwd_band(fasim_engine* E, const UnitBatch& B, const std::vector<WindowPr
 		HIPOK(E->blist[c].ensure(sizeof(BandTry) * (size_t)n));
 		HIPOK(E->bslots[c].ensure(sizeof(uint16_t) * BAND_SLOT_COLS * (size_t)n));
 	}
-	static const bool second = [] { const char* e = getenv("FASIM_BAND_SECOND"); return e ? atoi(e) != 0 : true; }();
+	const bool second = true;      // (a band that came back below its theta_min is followed by one chosen for the score it reached)
 	std::vector<int32_t> idx, tgt2, prev2;
 	const bool have_prev = prev && (int)prev->size() == n && E->lane_ub.p;
 	for (int pass = 0; pass < (second ? 2 : 1); pass++) {
@@ -969,7 +956,7 @@ int run_fwd_band(fasim_engine* E, const UnitBatch& B, const std::vector<WindowPr
 		BandSelLaunch S;
 		if (psrc) { S.prev_ub = E->lane_ub.as<uint16_t>(); S.prev = E->bprev.as<int32_t>(); }
 		S.probs = E->fprobs.as<FwdProb>(); S.target = E->btarget.as<int32_t>(); S.idx = pass ? E->bidx.as<int32_t>() : nullptr; S.n = np; S.tstride = B.tstride;
-		S.ublk = E->ub_view ? E->ub_view : E->ublk.as<uint32_t>(); S.ublk_blocks = E->ublk_blocks; S.m = E->m; S.tcodes = tcv(E);
+		S.ublk = E->ublk.as<uint32_t>(); S.ublk_blocks = E->ublk_blocks; S.m = E->m; S.tcodes = tcv(E);
 		for (int c = 0; c < 3; c++) { S.list[c] = E->blist[c].as<BandTry>(); S.slots[c] = E->bslots[c].as<uint16_t>(); }
 		S.list_cap = (uint32_t)n; S.counts = E->bcounts.as<uint32_t>(); S.cursors = E->bcounts.as<uint32_t>() + BAND_COUNTS; S.dec = E->bdec.as<int4>();
 		S.out = E->fout.as<FwdOut>(); S.class_mask = mask;
@@ -992,19 +979,19 @@ int run_fwd_band(fasim_engine* E, const UnitBatch& B, const std::vector<WindowPr
 			rc = upload_async(E, E->btab, all.data(), sizeof(BandZoneTab) * all.size()); if (rc) return rc;
 			{ TimedScope ts(E, 9); he = launch_band_emit(S, E->st); }
 			if (he != hipSuccess) return fail(E, FASIM_E_HIP, "band_emit launch failed: %s", hipGetErrorString(he));
-			HIPOK(hipStreamSynchronize(E->st));       // (`first` and `all` are host stack / heap; st_heavy may be another stream)
+			HIPOK(hipStreamSynchronize(E->st));       // (`first` and `all` are host stack / heap)
 			GateScope gate(E);
 			for (int c = 0; c < 3; c++) {
 				if (!per_class[c]) continue;
 				BandLaunch L;
 				L.list = E->blist[c].as<BandTry>(); L.slots = E->bslots[c].as<uint16_t>(); L.tab = E->btab.as<BandZoneTab>() + toff[c]; L.nwg = (int)tabs[c].size(); L.cls = c;
 				L.qcodes = E->q2.as<uint8_t>(); L.m = E->m; L.out = E->fout.as<FwdOut>();
-				{ TimedScope ts(E, 8, E->st_heavy); he = launch_align_band(L, E->st_heavy); }
+				{ TimedScope ts(E, 8, E->st); he = launch_align_band(L, E->st); }
 				if (he != hipSuccess) return fail(E, FASIM_E_HIP, "align_band launch failed: %s", hipGetErrorString(he));
 				const int64_t cells = (int64_t)counts[BAND_COUNT_COLS + c] * 48 * (8 << c);
 				if (st) { st->band_tries += per_class[c]; st->band_cells += cells; st->cells_stage3 += cells; }
 			}
-			HIPOK(hipStreamSynchronize(E->st_heavy));
+			HIPOK(hipStreamSynchronize(E->st));
 		} else {
 			// nothing banded: every try of the pass is marked for the full-height kernel
 			HIPOK(hipMemcpyAsync(S.cursors, first, sizeof first, hipMemcpyHostToDevice, E->st));
@@ -1035,7 +1022,7 @@ int run_fwd_band(fasim_engine* E, const UnitBatch& B, const std::vector<WindowPr
 //   3. band pass of those tries with the new bounds.
 //   4. whatever is still unproven (scores that can meet the reference's Q2 / overflow behaviour, start lanes too far apart for a
 //      band) takes the full-height forward passes (8-bit with taint tracking, 16-bit where the maximum reaches 251).
-bool band_ready(const fasim_engine* E, const UnitBatch& B) { return band_mask(E) != 0 && (E->ub_view || E->ublk_units >= B.nunit) && E->ublk_blocks > 0; }
+bool band_ready(const fasim_engine* E, const UnitBatch& B) { return band_mask(E) != 0 && E->ublk_units >= B.nunit && E->ublk_blocks > 0; }
 int run_fwd_smart(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb>& W, const std::vector<int32_t>& target,
 	const std::vector<int32_t>* ru, const FwdZones* Z, std::vector<FwdOut>& fo, std::vector<char>* got_ru, fasim_scan_stats& st)
 {
@@ -1319,26 +1306,9 @@ int fasim_engine_create(int device, fasim_engine** out)
 	fasim_engine* E = new fasim_engine();
 	E->device = device;
 	he = hipSetDevice(device);
-	{
-		// FASIM_LIGHT_CUS=N: reserve N of the 256 CUs (spread evenly) for the latency-bound kernels; k_scan / k_align_fwd
-		// run on the others through a second, CU-masked stream
-		const char* envl = getenv("FASIM_LIGHT_CUS");
-		const int nl = envl ? atoi(envl) : 0;
-		if (he == hipSuccess && nl > 0 && nl < 256) {
-			uint32_t light[8] = { 0 }, heavy[8] = { 0 };
-			const int every = 256 / nl;
-			for (int cu = 0; cu < 256; cu++) { const bool l = (cu % every) == every - 1 && (cu / every) < nl; (l ? light : heavy)[cu >> 5] |= 1u << (cu & 31); }
-			he = hipExtStreamCreateWithCUMask(&E->st, 8, light);
-			if (he == hipSuccess) he = hipExtStreamCreateWithCUMask(&E->st_heavy, 8, heavy);
-		} else if (he == hipSuccess && getenv("FASIM_STREAM_PRIO") && atoi(getenv("FASIM_STREAM_PRIO")) > 0) {
-			// FASIM_STREAM_PRIO=1: the latency-bound kernels of a batch on a high-priority stream, k_scan / k_align_fwd on a
-			// low-priority one (measured: see DESIGN.md section 4)
-			int least = 0, greatest = 0;
-			he = hipDeviceGetStreamPriorityRange(&least, &greatest);
-			if (he == hipSuccess) he = hipStreamCreateWithPriority(&E->st, hipStreamDefault, greatest);
-			if (he == hipSuccess) he = hipStreamCreateWithPriority(&E->st_heavy, hipStreamDefault, least);
-		} else if (he == hipSuccess) { he = hipStreamCreate(&E->st); E->st_heavy = E->st; }
-	}
+	// one stream per engine (CU-masked and prioritised second streams for the two VALU-bound kernels were measured in round 2 and
+	// lost: DESIGN.md section 4)
+	if (he == hipSuccess) he = hipStreamCreate(&E->st);
 	if (he != hipSuccess) { int rc = fail(nullptr, FASIM_E_NODEVICE, "cannot initialise device %d: %s", device, hipGetErrorString(he)); delete E; return rc; }
 	E->lut1 = make_lut(true); E->lut2 = make_lut(false);
 	std::vector<uint8_t> lut(48 * 256);
@@ -1362,7 +1332,6 @@ int fasim_engine_create(int device, fasim_engine** out)
 void fasim_engine_destroy(fasim_engine* e)
 {
 	if (!e) return;
-	if (e->reaper.joinable()) e->reaper.join();
 	for (fasim_engine* w : e->workers) fasim_engine_destroy(w);
 	e->workers.clear();
 	(void)hipSetDevice(e->device);
@@ -1378,7 +1347,6 @@ void fasim_engine_destroy(fasim_engine* e)
 	for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
 	for (DevBuf* b : bufs) b->release();
 	if (e->pin_dna) (void)hipHostFree(e->pin_dna);
-	if (e->st_heavy && e->st_heavy != e->st) (void)hipStreamDestroy(e->st_heavy);
 	if (e->st) (void)hipStreamDestroy(e->st);
 	delete e;
 }
@@ -1396,8 +1364,6 @@ int fasim_set_option(fasim_engine* E, const char* key, int32_t value)
 	else if (!strcmp(key, "hazard_hot_weight")) E->hz_hot_w = value > 0 ? std::min(32, value) : 0;
 	else if (!strcmp(key, "host_threads")) { if (value > 0) { E->host_threads = value; E->host_threads_total = value; E->host_threads_explicit = true; } }   // host side of the batches (all workers together)
 	else if (!strcmp(key, "band")) E->opt_band = value;                   // banded stage-3 forward pass: 0 off, 1 on (-1: default / FASIM_BAND)
-	else if (!strcmp(key, "tail_split")) E->opt_tail_split = value > 0 ? value : 0;
-	else if (!strcmp(key, "tail_items")) E->opt_tail_items = value;
 	else return fail(E, FASIM_E_ARG, "unknown option %s", key);
 	return FASIM_OK;
 }
@@ -1742,8 +1708,6 @@ struct BatchCtx {
 	std::vector<int32_t> sstart, slen; std::vector<int64_t> sidx;
 	std::vector<int32_t> hoff, hcnt, thr; std::vector<uint32_t> hits;
 	std::vector<char> seg_acgtn;
-	const uint8_t* tcodes_dev = nullptr;
-	const uint32_t* ublk_dev = nullptr; int ublk_blocks = 0;      // block maxima of the batch's k_scan pass (banded stage 3); NULL: none
 	const char* dna = nullptr; const fasim_params* p = nullptr; const std::vector<int>* encs = nullptr;
 	std::vector<std::vector<HostTriplex>> per_unit;     // [unit]: records of the unit after fastSIM's own filter
 	bool stage3_done = false;                           // -F: the whole batch was finished in the scan phase
@@ -1903,8 +1867,6 @@ int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t*
 			return FASIM_OK;
 		}
 		// the scan phase ends here: stage 3 runs per unit range (stage3_range), on this engine or on helpers
-		C.tcodes_dev = E->tcodes.as<uint8_t>();
-		C.ublk_dev = E->ublk_units >= B.nunit ? E->ublk.as<uint32_t>() : nullptr; C.ublk_blocks = E->ublk_blocks;
 		C.per_unit.assign((size_t)B.nunit, std::vector<HostTriplex>());
 		C.seg_acgtn.resize((size_t)nseg);
 		for (int s = 0; s < nseg; s++) C.seg_acgtn[(size_t)s] = only_acgtn(dna + sidx[(size_t)s] * step, slen[(size_t)s]) ? 1 : 0;
@@ -1925,11 +1887,6 @@ int stage3_range(fasim_engine* E, BatchCtx& C, int ua, int ub, fasim_scan_stats&
 	const int nenc = C.nenc;
 	const std::vector<int32_t>& slen = C.slen; const std::vector<int64_t>& sidx = C.sidx;
 	const std::vector<int32_t>& hoff = C.hoff; const std::vector<int32_t>& hcnt = C.hcnt; const std::vector<uint32_t>& hits = C.hits;
-	struct ViewScope {
-		fasim_engine* e; int blocks;
-		ViewScope(fasim_engine* e_, const BatchCtx& c) : e(e_), blocks(e_->ublk_blocks) { e->tc_view = c.tcodes_dev; e->ub_view = c.ublk_dev; if (c.ublk_dev) e->ublk_blocks = c.ublk_blocks; }
-		~ViewScope() { e->tc_view = nullptr; e->ub_view = nullptr; e->ublk_blocks = blocks; }
-	} view(E, C);
 	double t0;
 	{
 
@@ -1969,8 +1926,7 @@ int stage3_range(fasim_engine* E, BatchCtx& C, int ua, int ub, fasim_scan_stats&
 		bool v2 = true;
 		{ std::vector<WindowProb> probe(1, WindowProb{ 0, 0, 1 }); v2 = align_v2_fits(E, probe); }
 		// lane maxima left by the reverse passes (start-based bounds of a candidate's tries): [candidate][4 zones][lanes]
-		static const bool rev_bounds = [] { const char* e = getenv("FASIM_BAND_REV"); return e ? atoi(e) != 0 : true; }();
-		const bool zb = v2 && rev_bounds && band_ready(E, B) && !cs.empty() &&
+		const bool zb = v2 && band_mode(E) == 1 && band_ready(E, B) && !cs.empty() &&
 			E->lane_ub.ensure((size_t)cs.size() * 4 * 128 * systolic_tiles(E->m) * sizeof(uint16_t)) == hipSuccess;
 		if (v2 && !zb) { (void)hipGetLastError(); E->lane_ub.release(); }
 		if (v2) {
@@ -1989,8 +1945,8 @@ int stage3_range(fasim_engine* E, BatchCtx& C, int ua, int ub, fasim_scan_stats&
 				// Band targets.  A candidate that has been through a reverse pass has start-based bounds for all of its tries (its
 				// exact score is then known to the selection kernel); otherwise the first try aims at the candidate's own score (an
 				// accepted try reaches it), and a later try goes straight to the reverse pass, or, without reverse passes
-				// (FASIM_BAND_REV=0), aims at a fraction of the previous try's score.
-				static const int rho = [] { const char* e = getenv("FASIM_BAND_RHO"); const int v = e ? atoi(e) : 85; return v < 10 ? 10 : (v > 100 ? 100 : v); }();
+				// (band = 2), aims at 85 % of the previous try's score.
+				const int rho = 85;
 				std::vector<int32_t> target(W.size()), ru(zb ? W.size() : 0);
 				FwdZones Z;
 				if (zb) { Z.zones.resize(W.size()); Z.slot.resize(W.size()); }
@@ -2333,56 +2289,28 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 		const char* envw = getenv("FASIM_WORKERS");
 		if (envw) nworkers = std::max(1, std::min(16, atoi(envw)));
 		if (E->opt_workers > 0) nworkers = std::min(16, E->opt_workers);
-		// Fixed chunks of seg_batch segments.  FASIM_GUIDED=g (> 0) switches to guided self-scheduling (a chunk is about
-		// remaining / (g * workers), at least 64 segments) to shorten the tail of a scan; measured slower on the 50 Mb
-		// workload (every batch pays ~12 host round trips, so smaller batches cost more than the shorter tail saves).
-		static const double guided = [] { const char* e = getenv("FASIM_GUIDED"); return e ? atof(e) : 0.0; }();
-		// FASIM_TAPER=t (percent, default 0): the last t % of the segments go in half-size batches, so that the workers do not
-		// all finish their last batch at the same moment (shorter drain at the end of a scan)
-		static const int taper = [] { const char* e = getenv("FASIM_TAPER"); return e ? atoi(e) : -1; }();
-		int taper_pct = E->opt_taper >= 0 ? E->opt_taper : std::max(0, taper);
-		// Batch size fitted to the record (single-lncRNA scans of >= 128 segments per worker; FASIM_ADAPT=0, an explicit
-		// seg_batch or FASIM_GUIDED switch it off): the segments are cut so that every worker gets R whole rounds of batches
-		// of at most 512 segments (R = the fewest rounds that allow it), and the last quarter of the record goes in half-size
-		// batches.  The workers then neither
+		// option taper = t (percent): the last t % of the segments go in half-size batches, so that the workers do not all finish
+		// their last batch at the same moment (shorter drain at the end of a scan)
+		int taper_pct = E->opt_taper >= 0 ? E->opt_taper : 0;
+		// Batch size fitted to the record (single-lncRNA scans of >= 128 segments per worker; an explicit seg_batch switches it off): the segments are cut so that every worker gets R whole rounds of batches of at most 512 segments (R = the
+		// fewest rounds that allow it), and the last quarter of the record goes in half-size batches.  The workers then neither
 		// idle through a partial last round nor finish their last full-size batch all at once (the drain of a scan is the
 		// stage 3 of its last batches on an otherwise idle GPU): 50 Mb = 10 204 segments -> 15 batches of 511 + 10 of 255,
 		// 2.41 s against 2.61 s with fixed batches of 384 (profiles/r02_ab_batch_shape.txt: the optimum sits exactly where
 		// the batches tile the ten workers, 448 and 576 are both slower than 512; other record sizes: r02_ab_sizes.txt).
-		static const bool adapt = [] { const char* e = getenv("FASIM_ADAPT"); return e ? atoi(e) != 0 : true; }();
-		// (a batch of several lncRNAs is one stream of items, lncRNA after lncRNA, and keeps fixed batches of 384: with
-		//  FASIM_ADAPT_MULTI=1 -- the fitted batch size for all of them, the tapered quarter in the last one -- config 4 in small
-		//  is 2 % slower, tools/ab_cfg4.sh)
-		static const bool adapt_multi = [] { const char* e = getenv("FASIM_ADAPT_MULTI"); return e ? atoi(e) != 0 : false; }();
-		bool taper_last_only = false;
-		if (adapt && !envb && E->opt_seg_batch <= 0 && guided <= 0 && (nquery == 1 || adapt_multi) && seg_count >= (int64_t)128 * nworkers) {
-			taper_last_only = nquery > 1;
-			static const int64_t target = [] { const char* e = getenv("FASIM_BATCH_TARGET"); const int v = e ? atoi(e) : 512; return (int64_t)(v < 64 ? 64 : v); }();
+		// A batch of several lncRNAs is one stream of items, lncRNA after lncRNA, and keeps fixed batches of 384.
+		if (!envb && E->opt_seg_batch <= 0 && nquery == 1 && seg_count >= (int64_t)128 * nworkers) {
+			const int64_t target = 512;
 			const int64_t rounds = std::max<int64_t>(1, (seg_count + target * (int64_t)nworkers - 1) / (target * (int64_t)nworkers));
 			seg_batch = std::max<int64_t>(1, std::min<int64_t>((seg_count + rounds * nworkers - 1) / (rounds * nworkers), ((int64_t)8 << 30) / ((int64_t)4 * nenc * tstride)));
-			if (E->opt_taper < 0 && taper < 0) taper_pct = 25;
+			if (E->opt_taper < 0) taper_pct = 25;
 		}
-		std::vector<std::pair<int64_t, int64_t>> chunks, chunks_plain;
-		if (taper_last_only) {
-			for (int64_t b0 = seg_first, b_end = seg_first + seg_count; b0 < b_end; ) { const int64_t len = std::min(seg_batch, b_end - b0); chunks_plain.push_back({ b0, b0 + len }); b0 += len; }
-		}
+		std::vector<std::pair<int64_t, int64_t>> chunks;
 		{
 			int64_t b0 = seg_first; const int64_t b_end = seg_first + seg_count;
 			const int64_t taper_from = b_end - seg_count * taper_pct / 100;
-			// FASIM_STAGGER=1 (experiment): the first batch of every worker gets a different size (50 .. 95 % of a full one), so
-			// that the workers do not run their phases in lock step from the start
-			static const bool stagger = [] { const char* e = getenv("FASIM_STAGGER"); return e ? atoi(e) != 0 : false; }();
-			// FASIM_TAPER2=t (experiment): the very last t % of the segments in quarter-size batches
-			static const int taper2 = [] { const char* e = getenv("FASIM_TAPER2"); return e ? atoi(e) : 0; }();
-			const int64_t taper2_from = b_end - seg_count * taper2 / 100;
 			while (b0 < b_end) {
 				int64_t len = (taper_pct > 0 && b0 >= taper_from) ? std::max<int64_t>(1, seg_batch / 2) : seg_batch;
-				if (taper2 > 0 && b0 >= taper2_from && seg_batch >= 256) len = std::max<int64_t>(1, seg_batch / 4);
-				if (stagger && (int)chunks.size() < nworkers && seg_batch >= 128) len = seg_batch * (50 + 5 * (int64_t)chunks.size() * 10 / nworkers) / 100;
-				if (guided > 0) {
-					const int64_t g = (int64_t)((double)(b_end - b0) / (guided * nworkers)) + 1;
-					len = std::max<int64_t>(std::min<int64_t>(64, seg_batch), std::min<int64_t>(seg_batch, g));
-				}
 				len = std::min(len, b_end - b0);
 				chunks.push_back({ b0, b0 + len });
 				b0 += len;
@@ -2391,7 +2319,7 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 		struct Item { int q; int64_t b0, b1; };
 		std::vector<Item> items;
 		items.reserve(chunks.size() * (size_t)nquery);
-		for (int q = 0; q < nquery; q++) for (const auto& c : (taper_last_only && q + 1 < nquery) ? chunks_plain : chunks) items.push_back({ q, c.first, c.second });
+		for (int q = 0; q < nquery; q++) for (const auto& c : chunks) items.push_back({ q, c.first, c.second });
 		nworkers = (int)std::min<size_t>((size_t)nworkers, items.size());
 		// worker 0 is this engine; the others are lazily created engines on the same device
 		while ((int)E->workers.size() < nworkers - 1) {
@@ -2428,109 +2356,33 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 		std::vector<double> it0(items.size(), 0.0), it1(items.size(), 0.0);
 		std::vector<int> wrc(ws.size(), FASIM_OK);
 		std::atomic<size_t> next(0);
-		// Cooperative tail.  A worker owns an item through its scan phase (stages 1+2: its engine holds the target codes); the
-		// stage 3 of the LAST `tail_items` items is published as `tail_split` sub-tasks (unit ranges), which the owner and
-		// every worker that has run out of items work off together, so the end of a scan is not one batch's sequential rounds
-		// on an otherwise idle GPU.  Earlier items run their stage 3 as one piece on the owner (fewer, larger launches).
-		// OFF by default (tail_items 0): against the tree before this change, on the same box, it loses 0.1 s per 50 Mb scan (the
-		// split launches are less efficient than the idle time they fill: profiles/r02_ab_trees.txt).
-		static const int env_split = [] { const char* e = getenv("FASIM_TAIL_SPLIT"); return e ? atoi(e) : 4; }();
-		static const int env_tail = [] { const char* e = getenv("FASIM_TAIL_ITEMS"); return e ? atoi(e) : -1; }();
-		const int tail_split = std::max(1, E->opt_tail_split > 0 ? E->opt_tail_split : env_split);
-		const size_t tail_items = (size_t)std::max(0, E->opt_tail_items >= 0 ? E->opt_tail_items : (env_tail >= 0 ? env_tail : 0));
-		struct SubTask { size_t item; int ua, ub; };
-		struct BatchRun { BatchCtx ctx; std::atomic<int> pending{ 0 }; std::mutex mu; fasim_scan_stats st3; int rc = FASIM_OK; };
-		std::vector<std::unique_ptr<BatchRun>> runs(items.size());
-		std::mutex pool_mu; std::condition_variable pool_cv; std::deque<SubTask> pool; size_t items_finished = 0;
-		auto do_subtask = [&](fasim_engine* w, const SubTask& t) {
-			BatchRun& R = *runs[t.item];
-			const std::string& rq = queries[(size_t)items[t.item].q];
-			int r = FASIM_OK;
-			if (w->rna != rq) r = fasim_set_query(w, rq.data(), (int)rq.size());
-			fasim_scan_stats local; memset(&local, 0, sizeof local);
-			if (!r) r = stage3_range(w, R.ctx, t.ua, t.ub, local);
-			(void)hipStreamSynchronize(w->st);
-			drain_timed(w);
-			for (int k = 0; k < FASIM_KERNEL_FAMILIES; k++) { local.kernel_ms[k] = w->kernel_ms[k]; local.kernel_launches[k] = w->kernel_launches[k]; w->kernel_ms[k] = 0; w->kernel_launches[k] = 0; }
-			{
-				std::lock_guard<std::mutex> lk(R.mu);
-				add_stats(R.st3, local);
-				if (r && !R.rc) { R.rc = r; if (w != E) E->err = w->err; }
-			}
-			if (R.pending.fetch_sub(1) == 1) { std::lock_guard<std::mutex> lk(pool_mu); pool_cv.notify_all(); }
-		};
+		// A worker owns an item (one lncRNA x one batch of segments) from its scan phase (stages 1+2) through stage 3.
+		// (A cooperative tail -- the stage 3 of the last batches cut into sub-tasks that idle workers steal -- was built in round 2
+		//  and measured 0.1-0.2 s per 50 Mb scan slower than without it, profiles/r02_ab_trees.txt; it was removed in round 3.)
 		auto run = [&](size_t wi) {
 			CpuScope cpu(28, "CPU seconds: worker threads themselves (HIP calls, lists, decisions)");
 			(void)hipSetDevice(E->device);
 			fasim_engine* w = ws[wi];
-			bool retired = false;
 			for (;;) {
 				const size_t c = next.fetch_add(1);
-				if (c >= items.size() && !retired) { retired = true; active_workers.fetch_sub(1); }
-				if (c >= items.size()) {
-					// out of items: help with published stage-3 sub-tasks until every item is finished
-					SubTask t{ 0, 0, 0 }; bool have = false;
-					{
-						std::unique_lock<std::mutex> lk(pool_mu);
-						pool_cv.wait(lk, [&] { return !pool.empty() || items_finished == items.size(); });
-						if (!pool.empty()) { t = pool.front(); pool.pop_front(); have = true; }
-					}
-					if (!have) break;
-					do_subtask(w, t);
-					continue;
-				}
+				if (c >= items.size()) { active_workers.fetch_sub(1); break; }
 				const Item& itx = items[c];
 				const std::string& rq = queries[(size_t)itx.q];
 				it0[c] = now_s();
-				runs[c].reset(new BatchRun());
-				BatchRun& R = *runs[c];
-				memset(&R.st3, 0, sizeof R.st3);
+				BatchCtx ctx;
 				int r = FASIM_OK;
 				if (w->rna != rq) {          // the worker switches to this item's lncRNA (3 x m bytes H2D)
 					r = fasim_set_query(w, rq.data(), (int)rq.size());
 					if (r && w != E) w->err = std::string("worker set_query failed: ") + w->err;
 				}
-				if (!r) r = scan_batch(w, dna, dna_len, dna_dev, shard_lo, itx.b0, itx.b1, p, encs, tstride, R.ctx, ist[c]);
+				if (!r) r = scan_batch(w, dna, dna_len, dna_dev, shard_lo, itx.b0, itx.b1, p, encs, tstride, ctx, ist[c]);
+				if (!r && ctx.B.nunit > 0 && !ctx.stage3_done) r = stage3_range(w, ctx, 0, ctx.B.nunit, ist[c]);
 				(void)hipStreamSynchronize(w->st);
 				drain_timed(w);
 				for (int k = 0; k < FASIM_KERNEL_FAMILIES; k++) { ist[c].kernel_ms[k] = w->kernel_ms[k]; ist[c].kernel_launches[k] = w->kernel_launches[k]; w->kernel_ms[k] = 0; w->kernel_launches[k] = 0; }
-				const int nunit = R.ctx.B.nunit;
-				if (!r && nunit > 0 && !R.ctx.stage3_done) {
-					const bool in_tail = items.size() - c <= tail_items;
-					const int nsub = in_tail ? std::max(1, std::min(tail_split, R.ctx.nseg)) : 1;
-					if (nsub == 1) { R.pending.store(1); do_subtask(w, SubTask{ c, 0, nunit }); }
-					else {
-						std::vector<SubTask> subs;
-						for (int k = 0; k < nsub; k++) {           // whole segments per sub-task
-							const int s0 = (int)((int64_t)R.ctx.nseg * k / nsub), s1 = (int)((int64_t)R.ctx.nseg * (k + 1) / nsub);
-							if (s1 > s0) subs.push_back(SubTask{ c, s0 * R.ctx.nenc, s1 * R.ctx.nenc });
-						}
-						R.pending.store((int)subs.size());
-						{ std::lock_guard<std::mutex> lk(pool_mu); for (const SubTask& t : subs) pool.push_back(t); }
-						pool_cv.notify_all();
-						// the owner works the pool (its own sub-tasks and others') until its batch is complete
-						for (;;) {
-							SubTask t{ 0, 0, 0 }; bool have = false;
-							{
-								std::unique_lock<std::mutex> lk(pool_mu);
-								pool_cv.wait(lk, [&] { return !pool.empty() || R.pending.load() == 0; });
-								if (R.pending.load() == 0) break;
-								if (!pool.empty()) { t = pool.front(); pool.pop_front(); have = true; }
-							}
-							if (have) do_subtask(w, t);
-						}
-					}
-					if (R.rc) r = R.rc;
-				}
-				if (!r) {
-					collect_batch(R.ctx, per_item[c]);
-					add_stats(ist[c], R.st3);
-				}
+				if (!r) collect_batch(ctx, per_item[c]);
 				it1[c] = now_s();
-				runs[c].reset();                               // frees the batch's host tables
 				if (r) wrc[wi] = r;
-				{ std::lock_guard<std::mutex> lk(pool_mu); items_finished++; }
-				pool_cv.notify_all();
 			}
 			(void)hipStreamSynchronize(w->st);
 		};
@@ -2564,13 +2416,10 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 		if (nquery == 1) outs[0]->stats.t_total_s = now_s() - t_begin;
 		if (g_prof.on) fprintf(stderr, "[fasim prof] scan tail: packing the records                        %.3f s\n", now_s() - t_merge);
 		// Free the batches' lists (half a million strings for a 50 Mb record) here, side by side on the host threads, while the
-		// GPU is idle: left to a background thread (FASIM_REAPER=1) the unmapping runs into the first kernels of the caller's
-		// next scan and stretches them by half (the driver's MMU notifier stalls the queues while the address space changes:
-		// tools/iso_probe.py).
-		static const bool background = [] { const char* e = getenv("FASIM_REAPER"); return e && atoi(e) != 0; }();
-		if (E->reaper.joinable()) E->reaper.join();
-		if (background) E->reaper = std::thread([garbage = std::move(per_item)]() mutable { garbage.clear(); });
-		else {
+		// GPU is idle: left to a background thread the unmapping runs into the first kernels of the caller's next scan and
+		// stretches them by half (the driver's MMU notifier stalls the queues while the address space changes: tools/iso_probe.py,
+		// profiles/r02_ab_reaper.txt).
+		{
 			std::atomic<size_t> nextf(0);
 			auto freer = [&]() { for (;;) { const size_t c = nextf.fetch_add(1); if (c >= per_item.size()) break; std::vector<HostTriplex>().swap(per_item[c]); } };
 			const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, E->host_threads_total), per_item.size()));

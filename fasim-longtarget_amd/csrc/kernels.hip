@@ -415,9 +415,9 @@ static hipError_t launch_striped_t(const StripedLaunch& L, hipStream_t st)
 	// up to four 16-lane groups (problems) per one-wave workgroup; long queries get fewer groups so that one group's
 	// H/E/query stripes still fit the 160 KB of LDS
 	int groups = (int)(((size_t)160 * 1024 - (SHARED_Q ? qbytes : 0)) / gbytes);
-	// FASIM_STRIPED_GROUPS caps the problems per workgroup (default 4): two keep a workgroup's LDS below the ~20 KB that
+	// at most 4 problems per workgroup (a cap of two would keep a workgroup's LDS below the ~20 KB that
 	// four k_scan workgroups leave free on a CU, so these latency-bound kernels can start while a scan is running
-	static const int max_groups = [] { const char* e = getenv("FASIM_STRIPED_GROUPS"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+	const int max_groups = 4;
 	if (L.spread) { if (groups > 16) groups = 16; }        // four waves of four problems: the whole CU (see below)
 	else if (groups > max_groups) groups = max_groups;
 	if (groups < 1) return hipErrorInvalidValue;           // query too long for the LDS-resident kernel

@@ -60,18 +60,18 @@ const char* fasim_last_error(const fasim_engine* e);   /* e may be NULL: last gl
 
 /* Tuning knobs (optional).  key "workers": batches kept in flight by fasim_scan (default 10, env FASIM_WORKERS);
  * key "seg_batch": segments per batch (default 384, env FASIM_SEG_BATCH); value <= 0 restores the default.
- * key "taper": percent of the segments scanned in half-size batches at the end (default 0, env FASIM_TAPER);
+ * key "taper": percent of the segments scanned in half-size batches at the end (default: 25 for a single-lncRNA scan whose batches are fitted to the record, else 0);
  * key "heavy_gate": k_scan / k_align_fwd launches in flight at once (default 3, env FASIM_HEAVY_GATE; 0 = no gate);
  * -1 restores the default of the last two.
  * key "host_threads": host threads for the host side of the batches, all workers of this engine together (default 3/8 of the
  * cores, at most 96, env FASIM_HOST_THREADS); several engines in one process should share the cores.
- * key "hazard_chunks" (1) / "hazard_snapshots" (1) / "hazard_chunk_cols" (200) / "hazard_hot_weight" (2): the stripe-faithful
+ * key "hazard_chunks" (1) / "hazard_snapshots" (0) / "hazard_chunk_cols" (200) / "hazard_hot_weight" (2): the stripe-faithful
  * re-run of the units the reference's signed lazy-F exit can touch: in parallel column chunks from checkpoints (0: one
- * sequential run per unit), checkpoint pass continued from pipeline snapshots of the main scan (0: from column 0), cost target
- * of a chunk in columns, price of a column whose maximum is >= 144 (env FASIM_HAZARD_CHUNKS, _SNAP, _CHUNK_COLS, _HOT_W).
- * Results do not depend on any of them.
- * key "tail_split" / "tail_items": cooperative tail of a scan: the stage 3 of the last `tail_items` batches (default 0: off)
- * is cut into `tail_split` unit ranges (default 4) that idle workers take over (env FASIM_TAIL_SPLIT, FASIM_TAIL_ITEMS). */
+ * sequential run per unit), checkpoint pass continued from pipeline snapshots of the main scan (0: from column 0; the snapshots
+ * cost 64 KB of HBM writes per unit), cost target of a chunk in columns, price of a column whose maximum is >= 144
+ * (env FASIM_HAZARD_CHUNKS, FASIM_HAZARD_SNAP).
+ * key "band" (1): the banded forward pass of stage 3 (csrc/band.hip); 0 = every window try runs over the whole query (env FASIM_BAND).
+ * Results do not depend on any of them. */
 int fasim_set_option(fasim_engine* e, const char* key, int32_t value);
 
 /* Replaces ssw_init()/init_destroy() (ssw.h:78,83) and init_work() (stats.h:386): the lncRNA is

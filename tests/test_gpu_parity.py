@@ -777,15 +777,14 @@ def test_cli_classic_sim_writes_reference_files(golden_dir, tmp_path):
 # ---- edge cases of the round-2 paths ---------------------------------------------------------------------------------------
 def test_scan_queries_mixed_query_classes(mod, golden_dir, h19):
     """One batch with a 100-nt query (stripe-faithful kernels only), H19 (one systolic tile) and MALAT1 (three tiles): the
-    workers and the helpers of the cooperative tail switch query and kernel variant from item to item; every result equals the
-    scan of that query alone."""
+    workers switch query and kernel variant (striped, systolic, banded) from item to item; every result equals the scan of that
+    query alone."""
     _, q100 = synth.read_fasta(os.path.join(golden_dir, "h19_100.fa"))
     _, malat = synth.read_fasta(os.path.join(golden_dir, "MALAT1.fa"))
     _, dna = synth.read_fasta(os.path.join(golden_dir, "planted40k.fa"))
     p = mod.default_params(cLength=30)
     e = mod.Engine(0)
     e.set_option("seg_batch", 3)           # several items per query
-    e.set_option("tail_items", 4)          # cooperative tail on (off by default): the last items' stage 3 is shared among workers
     rnas = [q100, h19, malat, h19[:1600]]
     batch = e.scan_queries(rnas, dna, p)
     for q, rna in enumerate(rnas):

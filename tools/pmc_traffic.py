@@ -45,10 +45,13 @@ def main():
                              "WRITE_SIZE_KB_sum": round(w[k][0], 1), "WRITE_SIZE_launches": w[k][1]}
     units = b["counts"]["units"] + b["isolated_kernels"].get("units", 0)
     tries = b["counts"]["align_calls"] + b["isolated_kernels"].get("align_calls", 0)
-    for name, key, per in (("k_scan", "fasim::k_scan<", units), ("k_align_fwd", "fasim::k_align_fwd<", tries)):
+    band_tries = b["counts"].get("band_tries", 0) + b["isolated_kernels"].get("band_tries", 0)
+    for name, key, per in (("k_scan", "fasim::k_scan<", units), ("k_align_fwd", "fasim::k_align_fwd<", tries),
+                           ("k_align_band", "fasim::k_align_band<", band_tries), ("k_band_decide", "fasim::k_band_decide", tries),
+                           ("k_band_emit", "fasim::k_band_emit", tries)):
         fk = sum(v[0] for k, v in f.items() if k.startswith(key))
         wk = sum(v[0] for k, v in w.items() if k.startswith(key))
-        doc[name] = {"fetch_KB": round(fk, 1), "write_KB": round(wk, 1), "per": "unit" if name == "k_scan" else "window try",
+        doc[name] = {"fetch_KB": round(fk, 1), "write_KB": round(wk, 1), "per": "unit" if name == "k_scan" else ("band try" if name == "k_align_band" else "window try"),
                      "count_in_run": per,
                      "hbm_bytes_per_item": round((2 * fk + wk) * 1024 / max(1, per), 1),
                      "note": "fetch doubled (gfx950 FETCH_SIZE counts 64 B per 128-B request)"}

@@ -23,9 +23,6 @@ if len(sys.argv) > 1:
 for c in combos:
     sb, w = c[0], c[1]
     taper, gate = (c[2] if len(c) > 2 else 0), (c[3] if len(c) > 3 else 3)
-    split, tail = (c[4] if len(c) > 4 else 0), (c[5] if len(c) > 5 else -1)
-    eng.set_option("tail_split", split)
-    eng.set_option("tail_items", tail)
     eng.set_option("seg_batch", sb)
     eng.set_option("workers", w)
     eng.set_option("taper", taper)
@@ -37,4 +34,4 @@ for c in combos:
         ts.append(time.perf_counter() - t0)
         n = r.count
         del r
-    print(f"seg_batch {sb:4d} workers {w:2d} taper {taper:2d} gate {gate} tail_split {split} tail_items {tail}: mean {sum(ts) / len(ts):.3f} min {min(ts):.3f} s (runs {' '.join(f'{t:.3f}' for t in ts)}), {n} records", flush=True)
+    print(f"seg_batch {sb:4d} workers {w:2d} taper {taper:2d} gate {gate}: mean {sum(ts) / len(ts):.3f} min {min(ts):.3f} s (runs {' '.join(f'{t:.3f}' for t in ts)}), {n} records", flush=True)
