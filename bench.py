@@ -91,6 +91,9 @@ def host_cores():
     return max(1, min(n, 64))
 
 
+REF_EXTRA_ARGS = []       # e.g. ["-na", "1000"] (set from --nt-max)
+
+
 def _ref_run(wd, name, dna, rna_path, m, cells_out):
     """one reference process on one slice (the reference is single-threaded); returns the Popen"""
     d = os.path.join(wd, name)
@@ -99,7 +102,7 @@ def _ref_run(wd, name, dna, rna_path, m, cells_out):
     shutil.copyfile(rna_path, os.path.join(d, "rna.fa"))
     cells_out.append(m * sum(min(5000, len(dna) - s) for s in range(0, len(dna), 4900)) * 48)
     ref = os.path.join(ROOT, "oracle", "_ref", "fasim_ref")
-    return subprocess.Popen([ref, "-f1", "sample.fa", "-f2", "rna.fa", "-O", "out/"], cwd=d, stdout=subprocess.DEVNULL,
+    return subprocess.Popen([ref, "-f1", "sample.fa", "-f2", "rna.fa", "-O", "out/"] + REF_EXTRA_ARGS, cwd=d, stdout=subprocess.DEVNULL,
                             stderr=subprocess.DEVNULL)
 
 
@@ -158,6 +161,10 @@ def main():
     ap.add_argument("--dna-mb", type=float, default=50.0, help="million nt of synthetic DNA per rank (default 50)")
     ap.add_argument("--dna", choices=["random", "genome", "planted"], default="random")
     ap.add_argument("--lncrnas", type=int, default=0, help="K > 0: K synthetic 3 kb lncRNAs as one batch (BASELINE config 4)")
+    ap.add_argument("--rna", default="", help="comma-separated lncRNAs instead of H19: FASTA paths (relative to the repo root) or syn:N = "
+                    "synth.random_rna(N, 515); several = one batch (BASELINE configs 3 and 5: tests/golden/MEG3.fa,tests/golden/MALAT1.fa,"
+                    "tests/golden/NEAT1.fa / syn:10000 with --nt-max 1000)")
+    ap.add_argument("--nt-max", type=int, default=0, help="-na of the reference (ntMax); 0 = default")
     ap.add_argument("--shard", action="store_true", help="one record of gpus x dna-mb, sharded by contiguous segment ranges")
     ap.add_argument("--cpu-sample-nt", type=int, default=250000)
     ap.add_argument("--cpu-cores", type=int, default=0, help="processes of the all-core CPU baseline (0 = all cores this process may use, at most 64)")
@@ -210,7 +217,16 @@ def main():
     rna_path = os.path.join(ROOT, "tests", "golden", "H19.fa")
     _, h19 = synth.read_fasta(rna_path)
     rnas = [synth.random_rna(3000, k + 1) for k in range(args.lncrnas)] if args.lncrnas > 0 else [h19]
-    m_sum = sum(len(r) for r in rnas)
+    rna_names = [f"syn3k_{k + 1}" for k in range(args.lncrnas)] if args.lncrnas > 0 else ["H19"]
+    if args.rna:
+        rnas, rna_names = [], []
+        for spec in args.rna.split(","):
+            if spec.startswith("syn:"):
+                rnas.append(synth.random_rna(int(spec[4:]), 515)); rna_names.append(f"syn{int(spec[4:])}")
+            else:
+                rnas.append(synth.read_fasta(spec if os.path.isabs(spec) else os.path.join(ROOT, spec))[1])
+                rna_names.append(os.path.splitext(os.path.basename(spec))[0])
+    multi = len(rnas) > 1 or args.lncrnas > 0
 
     def make_dna(n, k):
         """the k-th record of the workload (k = rank in the weak-scaling layout)"""
@@ -221,7 +237,9 @@ def main():
         return synth.planted_dna(n, 12345 + k, rnas[0])
 
     n = int(args.dna_mb * 1e6)
-    p = mod.default_params()
+    p = mod.default_params(ntMax=args.nt_max) if args.nt_max > 0 else mod.default_params()
+    if args.nt_max > 0:
+        REF_EXTRA_ARGS.extend(["-na", str(args.nt_max)])
     if args.shard:
         dna = make_dna(n * world, 0)                       # every rank generates the same record and scans its shard of it
         seg_first, seg_count = mod.shard_segments(mod.segment_count(len(dna), p), rank, world)
@@ -229,11 +247,11 @@ def main():
         dna = make_dna(n, rank)
         seg_first, seg_count = 0, -1
     eng.load_dna(dna)                      # resident in HBM before the timed region
-    if args.lncrnas <= 0:
-        eng.set_query(h19)
+    if not multi:
+        eng.set_query(rnas[0])
 
     def step():
-        if args.lncrnas > 0:
+        if multi:
             res = eng.scan_queries(rnas, None, p, seg_first, seg_count)
         else:
             res = [eng.scan(None, p, seg_first, seg_count)]
@@ -282,13 +300,18 @@ def main():
     # untimed extra pass for the kernel-quality figures: ONE batch in flight, so every HIP-event duration is that of a
     # kernel that has the GPU to itself (exclusive); first lncRNA of the workload, first <= 1024 segments of the shard
     iso = None
+    iso_all = []
     if rank == 0:
-        eng.set_query(rnas[0])
         eng.set_option("workers", 1)
-        eng.set_option("seg_batch", 1024)
         total_seg = mod.segment_count(len(dna), p)
         have = seg_count if seg_count >= 0 else total_seg
-        iso = eng.scan(None, p, seg_first, min(1024, have)).stats
+        for q, r in enumerate(rnas[:4]):
+            # (about 14 M cells per unit for H19: a batch of 1024 segments; longer lncRNAs get proportionally fewer segments)
+            nseg_iso = max(64, min(1024, int(1024 * 2812 / len(r))))
+            eng.set_query(r)
+            eng.set_option("seg_batch", nseg_iso)
+            iso_all.append(eng.scan(None, p, seg_first, min(nseg_iso, have)).stats)
+        iso = iso_all[0]
         eng.set_option("workers", 0)
         eng.set_option("seg_batch", 0)
 
@@ -344,7 +367,9 @@ def main():
                     "frac_of_plain_valu_nominal": round(cells_k * ops / t / 1e12 / VALU_PLAIN_PEAK_TOPS, 4)}
 
         executed = agg["cells_stage1"] + agg["cells_stage2"] + agg["cells_stage3"]
-        workload = (f"{args.lncrnas} synthetic 3000-nt lncRNAs (one batch)" if args.lncrnas > 0 else "H19 (2812 nt)") + \
+        qdesc = (f"{args.lncrnas} synthetic 3000-nt lncRNAs (one batch)" if args.lncrnas > 0 else
+                 " + ".join(f"{n} ({len(r)} nt)" for n, r in zip(rna_names, rnas)) + (" as one batch" if len(rnas) > 1 else ""))
+        workload = qdesc + (f", -na {args.nt_max}" if args.nt_max > 0 else "") + \
             f" x synthetic {args.dna} DNA, " + (f"ONE record of {args.dna_mb * world:g} Mb sharded over {world} GPU(s) by contiguous segment ranges"
                                                 if args.shard else f"{args.dna_mb:g} Mb per GPU (seed 12345+rank)") + \
             ", default parameters, 48 rule encodings, records gathered to rank 0"
@@ -394,13 +419,25 @@ def main():
             "hazard_reruns_ms_per_49152_units": round(ik[1] * 49152 / max(1, iso["units"]), 2),
             "hazard_launches": int(il[1]),
         }
+        if len(iso_all) > 1 or args.rna:
+            # per lncRNA: the same one-batch pass (exclusive kernel times) and what it says about the query
+            out["isolated_per_lncrna"] = [{
+                "lncrna": rna_names[q], "m": len(rnas[q]), "segments": st["segments"], "units": st["units"], "t_total_s": round(st["t_total_s"], 4),
+                "logical_gcells_per_s_one_batch_alone": round(st["logical_cells"] / max(1e-9, st["t_total_s"]) / 1e9, 1),
+                "candidates_per_unit": round(st["candidates"] / max(1, st["units"]), 2), "align_calls": st["align_calls"],
+                "band_tries": st["band_tries"], "band_proven": st["band_proven"], "rev_bound_passes": st["rev_bound_passes"],
+                "rev_exact": st["rev_exact"], "hazard_units": st["hazard_units"], "stage2_overflow_units": st["stage2_overflow_units"],
+                "cells_stage2": st["cells_stage2"], "cells_stage3": st["cells_stage3"],
+                "ms": {KERNEL_NAMES[i]: round(st["kernel_ms"][i], 2) for i in KERNEL_SHOWN},
+                "launches": {KERNEL_NAMES[i]: int(st["kernel_launches"][i]) for i in KERNEL_SHOWN},
+            } for q, st in enumerate(iso_all)]
         if not args.no_cpu_baseline and world == 1:       # the CPU baseline is reported at N = 1 only
             cores = args.cpu_cores if args.cpu_cores > 0 else host_cores()
             tmp_rna = None
             cpu_rna = rna_path
-            if args.lncrnas > 0:
+            if args.lncrnas > 0 or args.rna:
                 tmp_rna = tempfile.NamedTemporaryFile(suffix=".fa", delete=False)
-                tmp_rna.write(b">syn3k_1\n" + rnas[0] + b"\n")
+                tmp_rna.write(b">" + rna_names[0].encode() + b"\n" + rnas[0] + b"\n")
                 tmp_rna.close()
                 cpu_rna = tmp_rna.name
             nn = args.cpu_sample_nt

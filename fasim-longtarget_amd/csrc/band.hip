@@ -60,7 +60,7 @@ __device__ __forceinline__ void scan_lane_rows(int v, int seg_len, int vs, int* 
 struct BandSelArgs {
 	const FwdProb* probs; const int32_t* target; const int32_t* idx;   // idx: NULL = tries 0..n-1, else the tries to look at
 	int32_t n, tstride;
-	const uint32_t* ublk; int32_t ublk_blocks, ntiles;
+	const uint16_t* ublk; int32_t ublk_blocks, ntiles;
 	const uint16_t* prev_ub; const int32_t* prev;      // bounds from an earlier full-height pass of the candidate (see kernels.h)
 	int32_t m, seg16, vs, nl;            // nl = lanes of the band profile = ceil(16 * seg16 / 48)
 	int32_t zs;                          // zone stride in profile lanes: a band that starts in [z * zs, (z + 1) * zs) belongs to zone z
@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(256) k_band_decide(BandSelArgs a)
 			}
 		} else
 		for (int i = 0; i < a.ntiles; i++) {
-			const uint32_t* U = a.ublk + (((size_t)unit * a.ntiles + i) * a.ublk_blocks) * 64 + lane;
+			const uint16_t* U = a.ublk + (((size_t)unit * a.ntiles + i) * a.ublk_blocks) * 64 + lane;
 			const int b0 = (t0 + 2 * lane) / SCAN_UBLK_STEPS;
 			uint32_t x[5];
 #pragma unroll
@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(256) k_band_decide(BandSelArgs a)
 #pragma unroll
 			for (int j = 0; j < 5; j++) {
 				const int b = b0 + j;
-				const int lo = (int)((x[j] & 0xffffu) >> 1), hi = (int)(x[j] >> 17);         // 2 * value + taint per half
+				const int lo = (int)(x[j] & 0xffu), hi = (int)(x[j] >> 8);                   // one byte per virtual lane
 				if (b <= e0) u0 = lo > u0 ? lo : u0;
 				if (b >= s1 && b <= e1) u1 = hi > u1 ? hi : u1;
 			}

@@ -581,8 +581,8 @@ int run_scan_v2(fasim_engine* E, const UnitBatch& B, const std::vector<char>& un
 	E->ublk_units = 0; E->ublk_blocks = 0;
 	if (band_mask(E)) {
 		const int nb = scan_ublk_blocks(B.tstride);
-		if (E->ublk.ensure((size_t)nu * systolic_tiles(E->m) * nb * 64 * sizeof(uint32_t)) == hipSuccess) {
-			L.ublk = E->ublk.as<uint32_t>(); L.ublk_blocks = nb; E->ublk_units = nu; E->ublk_blocks = nb;
+		if (E->ublk.ensure((size_t)nu * systolic_tiles(E->m) * nb * 64 * sizeof(uint16_t)) == hipSuccess) {
+			L.ublk = E->ublk.as<uint16_t>(); L.ublk_blocks = nb; E->ublk_units = nu; E->ublk_blocks = nb;
 		} else (void)hipGetLastError();
 	}
 	{
@@ -956,7 +956,7 @@ int run_fwd_band(fasim_engine* E, const UnitBatch& B, const std::vector<WindowPr
 		BandSelLaunch S;
 		if (psrc) { S.prev_ub = E->lane_ub.as<uint16_t>(); S.prev = E->bprev.as<int32_t>(); }
 		S.probs = E->fprobs.as<FwdProb>(); S.target = E->btarget.as<int32_t>(); S.idx = pass ? E->bidx.as<int32_t>() : nullptr; S.n = np; S.tstride = B.tstride;
-		S.ublk = E->ublk.as<uint32_t>(); S.ublk_blocks = E->ublk_blocks; S.m = E->m; S.tcodes = tcv(E);
+		S.ublk = E->ublk.as<uint16_t>(); S.ublk_blocks = E->ublk_blocks; S.m = E->m; S.tcodes = tcv(E);
 		for (int c = 0; c < 3; c++) { S.list[c] = E->blist[c].as<BandTry>(); S.slots[c] = E->bslots[c].as<uint16_t>(); }
 		S.list_cap = (uint32_t)n; S.counts = E->bcounts.as<uint32_t>(); S.cursors = E->bcounts.as<uint32_t>() + BAND_COUNTS; S.dec = E->bdec.as<int4>();
 		S.out = E->fout.as<FwdOut>(); S.class_mask = mask;

@@ -71,8 +71,8 @@ struct ScanLaunch {
 	const ScanDumpItem* dump_items = nullptr;
 	const int32_t* dump_cols = nullptr;     // [chunk]: the column after which the DP state of all rows is wanted (ascending within an item)
 	uint16_t* dump_state = nullptr;         // [chunk][2][16 * ceil(m/16)]: H, then the reference's E
-	// block maxima for the banded stage 3 (band.hip): [unit][tile][ublk_blocks][64 lanes] dwords; NULL: not wanted
-	uint32_t* ublk = nullptr;
+	// block maxima for the banded stage 3 (band.hip): [unit][tile][ublk_blocks][64 lanes] x 2 bytes; NULL: not wanted
+	uint16_t* ublk = nullptr;
 	int32_t ublk_blocks = 0;
 };
 constexpr int SCAN_UBLK_STEPS = 64;       // pipeline steps per block of maxima
@@ -120,7 +120,7 @@ constexpr int BAND_MAX_ZONES = 16;
 constexpr int BAND_COUNT_COLS = 3 * BAND_MAX_ZONES, BAND_COUNT_HOT = BAND_COUNT_COLS + 3, BAND_COUNT_NOBAND = BAND_COUNT_COLS + 4, BAND_COUNTS = 64;
 struct BandSelLaunch {
 	const FwdProb* probs; const int32_t* target; const int32_t* idx; int32_t n, tstride;
-	const uint32_t* ublk; int32_t ublk_blocks; int32_t m; const uint8_t* tcodes;
+	const uint16_t* ublk; int32_t ublk_blocks; int32_t m; const uint8_t* tcodes;
 	// start-based bounds from the reverse pass of the candidate (k_align_fwd's lane maxima over the reversed problem):
 	// prev[k] = slot * 4 + zone (zone 0..3) or -1 (then the block maxima of k_scan bound the try); NULL: none
 	const uint16_t* prev_ub = nullptr; const int32_t* prev = nullptr;

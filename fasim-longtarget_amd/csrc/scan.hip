@@ -77,6 +77,13 @@ __device__ __forceinline__ int vshift0(int x)
 	return __builtin_amdgcn_alignbit(x, up, 16);
 }
 
+// two carried maxima (2 * value + taint each) -> two bytes min(value, 255)
+__device__ __forceinline__ uint16_t ublk_pack(v2u acc)
+{
+	const v2u v = __builtin_elementwise_min(acc >> (v2u){ 1, 1 }, (v2u){ 255, 255 });
+	return (uint16_t)(v[0] | (v[1] << 8));
+}
+
 constexpr int SCAN_RS = 24;                 // storage rows per virtual lane in the LDS profile
 constexpr int SCAN_LANE_STRIDE = 112;       // bytes: 2 halves x 24 rows x 2 B + 16 B pad (bank-conflict-free b128)
 constexpr int SCAN_CODE_STRIDE = 64 * SCAN_LANE_STRIDE;   // 7168 B, a multiple of the 256-B bank row
@@ -111,10 +118,10 @@ struct ScanArgs {
 	const int32_t* dump_cols;
 	uint16_t* dump_state;
 	int32_t rows_total;          // 16 * ceil(m/16)
-	// block maxima for the banded stage 3 (band.hip): per unit, query tile and block of SCAN_UBLK_STEPS pipeline steps one dword per
-	// lane = the maximum (as carried: 2 * value + taint) over the rows of the lane's two virtual lanes and the steps of the block;
-	// virtual lane v of the tile sees column c at step c + v.  [unit][tile][block][64 lanes]; NULL: not wanted
-	uint32_t* ublk;
+	// block maxima for the banded stage 3 (band.hip): per unit, query tile and block of SCAN_UBLK_STEPS pipeline steps two bytes per
+	// lane = the maximum H (capped at 255: anything from 148 on only means "not banded") over the rows of the lane's two virtual
+	// lanes and the steps of the block; virtual lane v of the tile sees column c at step c + v.  [unit][tile][block][64 lanes]; NULL: not wanted
+	uint16_t* ublk;
 	int32_t ublk_blocks;         // blocks per (unit, tile) in the buffer
 };
 
@@ -432,7 +439,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DUMP ?
 			if constexpr (!DUMP) {
 				// (steps come in pairs: a block of SCAN_UBLK_STEPS steps ends after an odd step)
 				if (((step + 1) & (SCAN_UBLK_STEPS - 1)) == SCAN_UBLK_STEPS - 1) {
-					if (a.ublk) a.ublk[(((size_t)unit * a.ntiles + a.tile) * a.ublk_blocks + (step / SCAN_UBLK_STEPS)) * 64 + lane] = (uint32_t)to_int(ubacc);
+					if (a.ublk) a.ublk[(((size_t)unit * a.ntiles + a.tile) * a.ublk_blocks + (step / SCAN_UBLK_STEPS)) * 64 + lane] = ublk_pack(ubacc);
 					ubacc = (v2u){ 0, 0 };
 				}
 			}
@@ -440,7 +447,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DUMP ?
 		if (step < nsteps) do_step(step);
 		if constexpr (!DUMP) {
 			// the last, partial block (nsteps - 1 is its last step unless the block was just closed)
-			if (a.ublk && (nsteps & (SCAN_UBLK_STEPS - 1)) != 0) a.ublk[(((size_t)unit * a.ntiles + a.tile) * a.ublk_blocks + ((nsteps - 1) / SCAN_UBLK_STEPS)) * 64 + lane] = (uint32_t)to_int(ubacc);
+			if (a.ublk && (nsteps & (SCAN_UBLK_STEPS - 1)) != 0) a.ublk[(((size_t)unit * a.ntiles + a.tile) * a.ublk_blocks + ((nsteps - 1) / SCAN_UBLK_STEPS)) * 64 + lane] = ublk_pack(ubacc);
 		}
 		if (a.unit_hz && __builtin_amdgcn_ballot_w64(to_int(hzacc) != 0) != 0ull && lane == 0) atomicOr(a.unit_hz + unit, 1);
 		if (!DUMP && a.unit_first && first_enter != 0x7fffffff && lane == 0) atomicMin(a.unit_first + unit, first_enter);
