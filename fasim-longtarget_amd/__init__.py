@@ -266,13 +266,35 @@ def shard_segments(nseg: int, rank: int, world: int):
     return first, base + (1 if rank < rem else 0)
 
 
+GATHER_CHUNK = 256 << 20      # bytes rank 0 stages on the device per transfer (two such buffers)
+
+
+def _pieces(sizes, rsz, tot_r):
+    """Transfer plan of gather_results: for every source rank k > 0 its records and its pool cut into pieces of at most
+    GATHER_CHUNK bytes: (k, offset in the sender's staging buffer, offset in the merged buffer, length)."""
+    out, roff, poff = [], 0, 0
+    for k, (a, b) in enumerate(sizes):
+        if k > 0:
+            for src0, dst0, n in ((0, roff, a), (a, tot_r + poff, b)):
+                o = 0
+                while o < n:
+                    ln = min(GATHER_CHUNK, n - o)
+                    out.append((k, src0 + o, dst0 + o, ln))
+                    o += ln
+        roff += a
+        poff += b
+    return out
+
+
 def gather_results(res: ScanResult, dist, rank: int, world: int, device: str = "cuda"):
     """The path's only exchange step: every rank contributes the records of its segment shard, rank 0 gets them
     merged in rank order (= canonical (segment, encoding, rank) order because shards are contiguous).
-    One all_gather of (records bytes, pool bytes), then grouped point-to-point transfers (RCCL send/recv over xGMI;
-    gloo in the CPU tests) that put every shard's records and pool straight at their final positions of one flat
-    buffer on rank 0; the pool offsets are then rebased in place (fasim_rebase_offsets).  No per-record work in
-    Python and no second copy of the merged records."""
+    One all_gather of (records bytes, pool bytes), then point-to-point transfers (RCCL send/recv over xGMI; gloo in
+    the CPU tests) that put every shard's records and pool at their final positions of ONE pinned host buffer on rank 0;
+    the pool offsets are then rebased in place (fasim_rebase_offsets).  No per-record work in Python and no second copy
+    of the merged records.  On the GPU path rank 0 never stages more than 2 x GATHER_CHUNK bytes on its device: piece i + 1
+    is received into one staging buffer while piece i leaves the other one for the host (at hg38 scale the merged records
+    are 4-5 GB)."""
     import torch
     if world == 1:
         return res
@@ -283,54 +305,53 @@ def gather_results(res: ScanResult, dist, rank: int, world: int, device: str = "
     gathered = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(world)]
     dist.all_gather(gathered, torch.tensor([nr, plen], dtype=torch.int64, device=device))
     sizes = [(int(s[0]), int(s[1])) for s in gathered]
-    pin = device != "cpu"
-    stage = torch.empty(max(1, nr + plen), dtype=torch.uint8, pin_memory=pin)
-    if nr:
-        C.memmove(stage.data_ptr(), rp, nr)
-    if plen:
-        C.memmove(stage.data_ptr() + nr, pp, plen)
-    mine = stage.to(device, non_blocking=True) if pin else stage
-    if rank != 0:
-        ops = []
-        if nr:
-            ops.append(dist.P2POp(dist.isend, mine[:nr], 0))
-        if plen:
-            ops.append(dist.P2POp(dist.isend, mine[nr:nr + plen], 0))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        return None
     tot_r = sum(a for a, _ in sizes)
     tot_p = sum(b for _, b in sizes)
-    flat = torch.empty(max(1, tot_r + tot_p), dtype=torch.uint8, device=device)     # [records of all shards][pools of all shards]
-    ops, roff, poff, layout = [], 0, 0, []
-    for k, (a, b) in enumerate(sizes):
-        layout.append((roff, a // rsz, poff))
-        if k == 0:
-            if a:
-                flat[roff:roff + a].copy_(mine[:a])
-            if b:
-                flat[tot_r + poff:tot_r + poff + b].copy_(mine[a:a + b])
-        else:
-            if a:
-                ops.append(dist.P2POp(dist.irecv, flat[roff:roff + a], k))
-            if b:
-                ops.append(dist.P2POp(dist.irecv, flat[tot_r + poff:tot_r + poff + b], k))
+    plan = _pieces(sizes, rsz, tot_r)
+    gpu = device != "cpu"
+    if rank != 0:
+        stage = torch.empty(max(1, nr + plen), dtype=torch.uint8, pin_memory=gpu)
+        if nr:
+            C.memmove(stage.data_ptr(), rp, nr)
+        if plen:
+            C.memmove(stage.data_ptr() + nr, pp, plen)
+        mine = stage.to(device, non_blocking=True) if gpu else stage
+        for k, src, _dst, ln in plan:
+            if k == rank:
+                dist.send(mine[src:src + ln], 0)
+        return None
+    host = torch.empty(max(1, tot_r + tot_p), dtype=torch.uint8, pin_memory=gpu)       # [records of all shards][pools of all shards]
+    base = host.data_ptr()
+    if nr:
+        C.memmove(base, rp, nr)                      # rank 0's own shard: host to host
+    if plen:
+        C.memmove(base + tot_r, pp, plen)
+    if not gpu:
+        for k, _src, dst, ln in plan:
+            dist.recv(host[dst:dst + ln], k)
+    elif plan:
+        bufs = [torch.empty(min(GATHER_CHUNK, max(ln for _, _, _, ln in plan)), dtype=torch.uint8, device=device) for _ in range(2)]
+        copy_stream = torch.cuda.Stream()
+        freed = [None, None]                         # event: the buffer's previous piece has left for the host
+        for i, (k, _src, dst, ln) in enumerate(plan):
+            b = i & 1
+            if freed[b] is not None:
+                freed[b].synchronize()
+            dist.recv(bufs[b][:ln], k)               # (RCCL recv is ordered on the current stream)
+            ready = torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(ready)
+                host[dst:dst + ln].copy_(bufs[b][:ln], non_blocking=True)
+                freed[b] = torch.cuda.Event()
+                freed[b].record()
+        copy_stream.synchronize()
+    roff = poff = 0
+    for a, b in sizes:
+        if a and poff:
+            L.fasim_rebase_offsets(base + roff, a // rsz, poff)
         roff += a
         poff += b
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
-    if pin:
-        host = torch.empty(flat.shape, dtype=torch.uint8, pin_memory=True)
-        host.copy_(flat, non_blocking=True)
-        torch.cuda.synchronize()
-    else:
-        host = flat
-    base = host.data_ptr()
-    for roff, n, poff in layout:
-        if n and poff:
-            L.fasim_rebase_offsets(base + roff, n, poff)
     return ScanResult(stats={}, _ext=(base, tot_r // rsz, base + tot_r, tot_p, host))
 
 

@@ -124,6 +124,7 @@ struct fasim_engine {
 	DevBuf ublk, btarget, bidx, bcounts, blist[3], bslots[3], bprev, lane_ub, fzones, fubslot, bdec, btab;
 	int ublk_units = 0, ublk_blocks = 0;         // units covered by `ublk` (0: none), blocks per (unit, tile)
 	int opt_band = -1;                           // option "band": 0 off, 1 on (-1 = default / environment FASIM_BAND)
+	int opt_numa = 1;                            // option "numa_affinity": pin the scan's host threads to the GPU's NUMA node (no-op on one node)
 };
 
 namespace {
@@ -341,6 +342,49 @@ static int band_mask(const fasim_engine* E)
 	if (!band_mode(E) || E->align_v1 || E->scan_v1) return 0;
 	return band_classes(E->m);
 }
+
+// CPUs of the NUMA node the GPU hangs on (local_cpulist of its PCI device), intersected with what this thread may use.  false:
+// unknown, or no restriction (single-node machine): nothing to pin.
+static bool gpu_local_cpus(int device, cpu_set_t* out)
+{
+	char bus[64] = { 0 };
+	if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); return false; }
+	for (char* c = bus; *c; c++) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+	char path[160]; snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", bus);
+	FILE* f = fopen(path, "r");
+	if (!f) return false;
+	char list[1024] = { 0 };
+	const bool ok = fgets(list, sizeof list, f) != nullptr;
+	fclose(f);
+	if (!ok) return false;
+	cpu_set_t local; CPU_ZERO(&local);
+	for (const char* p = list; *p && *p != '\n'; ) {
+		char* e = nullptr;
+		const long a = strtol(p, &e, 10);
+		if (e == p) break;
+		long b = a; p = e;
+		if (*p == '-') { b = strtol(p + 1, &e, 10); p = e; }
+		for (long k = a; k <= b && k < CPU_SETSIZE; k++) if (k >= 0) CPU_SET((int)k, &local);
+		if (*p == ',') p++;
+	}
+	cpu_set_t allowed;
+	if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return false;
+	CPU_AND(out, &local, &allowed);
+	const int n = CPU_COUNT(out);
+	return n > 0 && n < CPU_COUNT(&allowed);
+}
+// Pins the calling thread (and the worker / host threads it starts, which inherit the mask) to the GPU's NUMA node for the
+// duration of a scan: on an 8-GPU node every rank / every --devices engine then keeps its host side next to its own GPU
+// instead of wandering over both sockets.  Option numa_affinity = 0 leaves the affinity alone.
+struct AffinityScope {
+	cpu_set_t saved; bool active = false;
+	AffinityScope(int device, bool enabled) {
+		cpu_set_t local;
+		if (!enabled || sched_getaffinity(0, sizeof saved, &saved) != 0 || !gpu_local_cpus(device, &local)) return;
+		active = sched_setaffinity(0, sizeof local, &local) == 0;
+	}
+	~AffinityScope() { if (active) (void)sched_setaffinity(0, sizeof saved, &saved); }
+};
 
 // FASIM_HAZARD_CHUNKS=0: whole-unit re-run of the hazard units (the round-1 path); FASIM_HAZARD_SNAP=0: the checkpoint pass
 // runs every hazard unit from column 0 instead of from the main pass's pipeline snapshots (both for measurements)
@@ -1363,6 +1407,7 @@ int fasim_set_option(fasim_engine* E, const char* key, int32_t value)
 	else if (!strcmp(key, "hazard_chunk_cols")) E->hz_target = value > 0 ? std::max(64, value) : 0;
 	else if (!strcmp(key, "hazard_hot_weight")) E->hz_hot_w = value > 0 ? std::min(32, value) : 0;
 	else if (!strcmp(key, "host_threads")) { if (value > 0) { E->host_threads = value; E->host_threads_total = value; E->host_threads_explicit = true; } }   // host side of the batches (all workers together)
+	else if (!strcmp(key, "numa_affinity")) E->opt_numa = value != 0;
 	else if (!strcmp(key, "band")) E->opt_band = value;                   // banded stage-3 forward pass: 0 off, 1 on (-1: default / FASIM_BAND)
 	else return fail(E, FASIM_E_ARG, "unknown option %s", key);
 	return FASIM_OK;
@@ -2246,6 +2291,7 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 	if (dna_len > 0x7fffffffll) return fail(E, FASIM_E_ARG, "one record is limited to 2^31-1 nt (the reference's int positions)");
 	HIPOK(hipSetDevice(E->device));
 	const double t_begin = now_s();
+	AffinityScope numa(E->device, E->opt_numa != 0);
 	{ const char* pe = getenv("FASIM_PROFILE"); g_prof.on = pe && atoi(pe) != 0; g_prof.reset(); }
 
 	std::vector<std::string> queries;

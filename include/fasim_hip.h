@@ -70,6 +70,9 @@ const char* fasim_last_error(const fasim_engine* e);   /* e may be NULL: last gl
  * sequential run per unit), checkpoint pass continued from pipeline snapshots of the main scan (0: from column 0; the snapshots
  * cost 64 KB of HBM writes per unit), cost target of a chunk in columns, price of a column whose maximum is >= 144
  * (env FASIM_HAZARD_CHUNKS, FASIM_HAZARD_SNAP).
+ * key "numa_affinity" (1): for the duration of a scan the calling thread and the threads the scan starts are pinned to the CPUs of
+ * the GPU's NUMA node (/sys/bus/pci/devices/<bus id>/local_cpulist); the caller's affinity is restored afterwards; no effect on a
+ * single-node machine.
  * key "band" (1): the banded forward pass of stage 3 (csrc/band.hip); 0 = every window try runs over the whole query (env FASIM_BAND).
  * Results do not depend on any of them. */
 int fasim_set_option(fasim_engine* e, const char* key, int32_t value);

@@ -46,15 +46,20 @@ def records_for_segments(mod, units, seg_lo, seg_hi, c_length=40):
     return mod.ScanResult(b"".join(recs), bytes(pool), {})
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, bounds=None, chunk=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         mod = entry.load()
+        if chunk:
+            mod.GATHER_CHUNK = chunk                    # many small pieces per shard: the chunked transfer plan
         _, units = helpers.parse_scan(helpers.gunzip(os.path.join(GOLD, "planted40k.scan.gz")))
         nseg = max(u["seg"] for u in units) + 1
-        first, count = mod.shard_segments(nseg, rank, world)
+        if bounds is None:
+            first, count = mod.shard_segments(nseg, rank, world)
+        else:                                           # hand-made shards, some of them empty
+            first, count = bounds[rank], bounds[rank + 1] - bounds[rank]
         mine = records_for_segments(mod, units, first, first + count)
         merged = mod.gather_results(mine, dist, rank, world, "cpu")
         if rank == 0:
@@ -77,6 +82,17 @@ def test_sharded_scan_gathers_to_reference_output(tmp_path, world):
     out = tmp_path / "merged.TFOsorted"
     port = 29500 + (os.getpid() % 2000) + world
     mp.spawn(_worker, args=(world, port, str(out)), nprocs=world, join=True)
+    assert out.read_bytes() == open(os.path.join(GOLD, "planted40k.TFOsorted"), "rb").read()
+
+
+def test_eight_ranks_uneven_and_empty_shards_chunked_gather(tmp_path):
+    """World 8 (the node size of BASELINE config 4) with hand-made shards of 0, 0, 3, 0, 1, 5, 0, 0 segments and a 4 KB transfer
+    chunk (every shard goes in many pieces): the merged records and the -TFOsorted text equal the unsharded ones."""
+    if not os.path.exists(os.path.join(entry.PKG_DIR, "libfasim_hip.so")):
+        entry.build()
+    out = tmp_path / "merged8.TFOsorted"
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(8, port, str(out), [0, 0, 0, 3, 3, 4, 9, 9, 9], 4096), nprocs=8, join=True)
     assert out.read_bytes() == open(os.path.join(GOLD, "planted40k.TFOsorted"), "rb").read()
 
 
