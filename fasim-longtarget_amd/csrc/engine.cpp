@@ -967,7 +967,7 @@ int run_fwd_band(fasim_engine* E, const UnitBatch& B, const std::vector<WindowPr
 	const int n = (int)W.size();
 	fo.resize(n);
 	if (!n) return FASIM_OK;
-	ProfScope ps(28, "run_fwd_band total");
+	ProfScope ps(29, "run_fwd_band total");
 	const int mask = band_mask(E);
 	std::vector<FwdProb> probs(n);
 	for (int k = 0; k < n; k++) { probs[k].tbase = (int64_t)W[k].unit * B.tstride + W[k].t0; probs[k].len = W[k].len; probs[k].stream_off = W[k].unit; }      // (stream_off carries the unit here)
@@ -2378,7 +2378,7 @@ static int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rn
 		for (int k = 0; k < nworkers - 1; k++) ws.push_back(E->workers[k]);
 		{
 			const char* envg = getenv("FASIM_HEAVY_GATE");      // heavy kernels in flight at once (0 = no gate)
-			E->own_gate.cap = E->opt_gate >= 0 ? E->opt_gate : (envg ? atoi(envg) : 3);
+			E->own_gate.cap = E->opt_gate >= 0 ? E->opt_gate : (envg ? atoi(envg) : 4);
 		}
 		for (fasim_engine* w : ws) {
 			w->gate = (ws.size() > 1 && E->own_gate.cap > 0) ? &E->own_gate : nullptr;

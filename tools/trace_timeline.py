@@ -11,7 +11,7 @@ rows = []
 with open(path) as f:
     for r in csv.DictReader(f):
         n = r["Kernel_Name"]
-        heavy = (("k_scan<" in n) and ("false, true>" not in n)) or ("k_align_fwd" in n) or ("k_align_band" in n)   # (k_scan<.., true> = the checkpoint pass of the hazard re-run: a few hundred waves)
+        heavy = (("k_scan<" in n) and (", true>" not in n)) or ("k_align_fwd" in n) or ("k_align_band" in n)   # (k_scan<.., true> = the checkpoint pass of the hazard re-run: a few hundred waves)
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), heavy))
 t0 = min(r[0] for r in rows)
 t1 = max(r[1] for r in rows)
