@@ -71,7 +71,7 @@ struct AlignOutDev {           // 32-byte header; the CIGAR ops go to a compact 
 };
 
 // ---- row f3: forward sweep of classic SIM (sim.hip) ---------------------------------------------------
-struct SimEvent { uint32_t j, pad; uint64_t key; };     // a cell above the threshold: column (the row is implied by the buffer), (score + 2^20) << 26 | start_row << 13 | start_col
+struct SimEvent { uint32_t j, pad; uint64_t key; };     // a cell above the threshold: column (the row is implied by the buffer), (score + 2^23) << 32 | start_row << 16 | start_col
 struct SimNodeDev { int64_t score, stari, starj, endi, endj, top, bot, left, right; };   // = fasim_sim_node (fasim_hip.h)
 constexpr int SIM_K = 50;
 struct SimFwdArgs {

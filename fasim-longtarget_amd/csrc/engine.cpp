@@ -1518,7 +1518,7 @@ static int sim_forward_units(fasim_engine* E, const uint8_t* tcodes_dev, int tst
 	if (nrun <= 0) return FASIM_OK;
 	int maxlen = 1;
 	for (int u = 0; u < nrun; u++) maxlen = std::max(maxlen, unit_len_host[first + u]);
-	if (E->m > 8191 || maxlen > 8191) return fail(E, FASIM_E_UNSUPPORTED, "the SIM forward sweep holds start points in 13 bits: query %d / target %d nt is too long", E->m, maxlen);
+	if (E->m > 65535 || maxlen > 65535) return fail(E, FASIM_E_UNSUPPORTED, "the SIM forward sweep holds start points in 16 bits: query %d / target %d nt is too long", E->m, maxlen);
 	const int64_t row_stride = (maxlen + 2 + 15) & ~15;
 	const uint32_t cap = (uint32_t)((maxlen + 15) & ~15);
 	DevBuf& d_min = E->sim_min; DevBuf& d_row = E->sim_row; DevBuf& d_ev = E->sim_ev; DevBuf& d_cnt = E->sim_cnt; DevBuf& d_nodes = E->sim_nodes;

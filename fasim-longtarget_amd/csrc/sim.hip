@@ -16,9 +16,10 @@
 // point is one compare + ballot, the eviction of the first lowest-score node a wave minimum over (score, lane).  That is
 // the row-major order of the reference without a sort, and nothing but the 50 nodes ever leaves the GPU.
 //
-// A DP state = one 64-bit key  (score + SIM_BIAS) << 26 | start_row << 13 | start_col,  so ORDER is an unsigned 64-bit max
+// A DP state = one 64-bit key  (score + SIM_BIAS) << 32 | start_row << 16 | start_col,  so ORDER is an unsigned 64-bit max
 // and "score - k" is a subtraction in the top field.  Scores are the reference's x10 values (match 50, mismatch -40, gap
-// open 120, extension 40).  Limits: query and target at most 8191 long (13-bit start fields).
+// open 120, extension 40).  Limits: query and target at most 65535 long (16-bit start fields; 8191 until round 3).
+// Four units per 256-thread workgroup (one wave each: the waves share nothing).
 // Integer DP: no MFMA.  Plain 64-bit VALU arithmetic, not yet tuned.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -26,11 +27,12 @@
 
 namespace fasim {
 
-constexpr int64_t SIM_BIAS = 1 << 20;           // scores stay within (-2^20, 2^20): |gap run| <= 120 + 40 * 8191 < 2^19
-constexpr int SIM_SHIFT = 26;
+constexpr int64_t SIM_BIAS = 1 << 23;           // scores stay within (-2^23, 2^23): |gap run| <= 120 + 40 * 65535 < 2^22, best score 50 * 65535 < 2^22
+constexpr int SIM_SHIFT = 32;
+constexpr int SIM_FIELD = 16;                   // bits of the start row / start column fields
 constexpr int64_t SIM_MATCH = 50, SIM_MISMATCH = -40, SIM_Q = 120, SIM_R = 40;
 
-__device__ __forceinline__ uint64_t sim_key(int64_t s, uint32_t i, uint32_t j) { return ((uint64_t)(s + SIM_BIAS) << SIM_SHIFT) | ((uint64_t)i << 13) | (uint64_t)j; }
+__device__ __forceinline__ uint64_t sim_key(int64_t s, uint32_t i, uint32_t j) { return ((uint64_t)(s + SIM_BIAS) << SIM_SHIFT) | ((uint64_t)i << SIM_FIELD) | (uint64_t)j; }
 __device__ __forceinline__ int64_t sim_score(uint64_t k) { return (int64_t)(k >> SIM_SHIFT) - SIM_BIAS; }
 __device__ __forceinline__ uint64_t umax64(uint64_t a, uint64_t b) { return a > b ? a : b; }
 __device__ __forceinline__ uint64_t shfl_up64(uint64_t v)
@@ -44,10 +46,11 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l)
 	return ((uint64_t)hi << 32) | lo;
 }
 
-__global__ void __launch_bounds__(64) k_sim_forward(SimFwdArgs a)
+__global__ void __launch_bounds__(256) k_sim_forward(SimFwdArgs a, int32_t nunit)
 {
-	const int unit = blockIdx.x;
-	const int lane = threadIdx.x;
+	const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (unit >= nunit) return;
+	const int lane = threadIdx.x & 63;
 	const int N = a.unit_len[unit];
 	const int M = a.m;
 	const uint8_t* tc_unit = a.tcodes + (int64_t)unit * a.tstride;
@@ -124,7 +127,7 @@ __global__ void __launch_bounds__(64) k_sim_forward(SimFwdArgs a)
 				for (int x = 0; x < nb; x++) {
 					const int j = __builtin_amdgcn_readlane((int)ej, x);
 					const uint64_t key = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)khi, x) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)klo, x);
-					const int c = (int)sim_score(key), ci = (int)((key >> 13) & 0x1fff), cj = (int)(key & 0x1fff);
+					const int c = (int)sim_score(key), ci = (int)((key >> SIM_FIELD) & 0xffff), cj = (int)(key & 0xffff);
 					const unsigned long long hit = __ballot(lane < nn && n_stari == ci && n_starj == cj);
 					int target;
 					bool fresh;
@@ -162,7 +165,7 @@ __global__ void __launch_bounds__(64) k_sim_forward(SimFwdArgs a)
 hipError_t launch_sim_forward(const SimFwdArgs& a, int32_t nunit, hipStream_t st)
 {
 	if (nunit <= 0) return hipSuccess;
-	hipLaunchKernelGGL(k_sim_forward, dim3((unsigned)nunit), dim3(64), 0, st, a);
+	hipLaunchKernelGGL(k_sim_forward, dim3((unsigned)((nunit + 3) / 4)), dim3(256), 0, st, a, nunit);
 	return hipGetLastError();
 }
 

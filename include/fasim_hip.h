@@ -125,7 +125,7 @@ int fasim_encode_unit(const char* seg, int32_t n, int32_t enc, char* target, cha
  * does (sim.h:567).  fasim_scan with params.classicSim = 1 runs the whole -F path: this sweep on the GPU, then the
  * linear-space traceback, the region re-sweeps and the triplex records on host threads (csrc/host_sim.cpp).
  * Query and targets: ACGT (other letters score as mismatches; the reference reads an uninitialised table there), at most
- * 8191 long. */
+ * 65535 long (16-bit start fields in the 64-bit DP keys). */
 typedef struct fasim_sim_node { int64_t score, stari, starj, endi, endj, top, bot, left, right; } fasim_sim_node;
 #define FASIM_SIM_K 50
 typedef struct fasim_result fasim_result;      /* defined below */

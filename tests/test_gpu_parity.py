@@ -174,6 +174,30 @@ def test_hazard_rerun_variants_agree(mod, h19, golden_dir, fixture, qlen):
         assert results[k] == results[0], k
 
 
+@pytest.mark.parametrize("query,dna_file", [("H19.fa", "planted40k.fa"), ("H19.fa", "q2cat.fa"), ("MALAT1.fa", "malat1_dna.fa"), ("NEAT1.fa", "neat1_dna.fa")])
+def test_band_modes_agree(mod, golden_dir, query, dna_file):
+    """Stage 3 gives the same records whether every window try sweeps the whole query (band 0, the reference's organisation), or
+    row bands proven from k_scan's block maxima plus reverse passes (band 1, default), or the bands without reverse passes (band 2).
+    MALAT1 / NEAT1: queries whose band profile is staged per row zone (3 and 8 zones)."""
+    _, rna = synth.read_fasta(os.path.join(golden_dir, query))
+    _, dna = synth.read_fasta(os.path.join(golden_dir, dna_file))
+    p = mod.default_params(cLength=20)
+    results, stats = [], []
+    for band in (0, 1, 2):
+        e = mod.Engine(0)
+        e.set_option("band", band)
+        e.set_query(rna)
+        r = e.scan(dna, p)
+        results.append((r.recs, r.pool, r.stats["candidates"], r.stats["align_calls"]))
+        stats.append(r.stats)
+        e.close()
+    assert results[1] == results[0] and results[2] == results[0]
+    assert stats[0]["band_tries"] == 0 and stats[0]["kernel_launches"][8] == 0
+    assert stats[1]["band_proven"] > 0 and stats[1]["rev_bound_passes"] > 0 and stats[1]["kernel_launches"][8] > 0
+    assert stats[2]["band_proven"] > 0 and stats[2]["rev_bound_passes"] == 0
+    assert stats[1]["cells_stage3"] < stats[0]["cells_stage3"]
+
+
 @pytest.mark.parametrize("name", ["meg3", "malat1", "neat1"])
 def test_long_queries_scan(mod, engine, golden_dir, name):
     """MEG3 (1 582 nt, 1 query tile), MALAT1 (8 708 nt, 3 tiles) and NEAT1 (22 767 nt, 8 tiles): the systolic kernels run
@@ -752,6 +776,20 @@ def test_classic_sim_scan_end_to_end(mod, h19, golden_dir):
     dna2 = synth.planted_dna(12000, 909, h19, every=700)
     res = e.scan(dna2, p)
     assert res.triplexes() == _simscan_expected(golden_dir, "simF12k.simscan.gz", 20)
+    e.close()
+
+
+def test_classic_sim_long_query(mod, golden_dir):
+    """-F with MALAT1 (8 708 nt): start rows beyond the 13-bit fields of the first version of k_sim_forward (16-bit fields now);
+    every record equals the reference's own SIM() (`make_golden.py simF_long`)."""
+    _, malat = synth.read_fasta(os.path.join(golden_dir, "MALAT1.fa"))
+    _, dna = synth.read_fasta(os.path.join(golden_dir, "malat1F_dna.fa"))
+    e = mod.Engine(0)
+    e.set_query(malat)
+    res = e.scan(dna, mod.default_params(classicSim=1, cLength=20))
+    exp = _simscan_expected(golden_dir, "malat1F.simscan.gz", 20)
+    assert len(exp) > 0 and res.triplexes() == exp
+    assert res.stats["kernel_launches"][7] > 0
     e.close()
 
 
