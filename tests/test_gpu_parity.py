@@ -297,6 +297,25 @@ def test_systolic_and_stripe_faithful_paths_agree(mod, h19, golden_dir, monkeypa
     assert fast.stats["kernel_launches"][0] > 0 and slow.stats["kernel_launches"][0] == 0
 
 
+def test_scheduling_options_agree(mod, h19, golden_dir):
+    """Batches in flight, segments per batch, the gate of the VALU-bound kernels, host threads, the taper and the NUMA pinning only
+    shape the schedule: every setting gives the records of the default one."""
+    _, dna = synth.read_fasta(os.path.join(golden_dir, "planted40k.fa"))
+    p = mod.default_params(cLength=20)
+    results = []
+    for opts in ({}, {"workers": 1}, {"workers": 3, "seg_batch": 2}, {"workers": 16, "seg_batch": 1, "heavy_gate": 0},
+                 {"seg_batch": 4, "heavy_gate": 1, "host_threads": 2, "taper": 50}, {"numa_affinity": 0, "host_threads": 64}):
+        e = mod.Engine(0)
+        for k, v in opts.items():
+            e.set_option(k, v)
+        e.set_query(h19)
+        r = e.scan(dna, p)
+        results.append((r.recs, r.pool, r.stats["units"], r.stats["candidates"]))
+        e.close()
+    for k in range(1, len(results)):
+        assert results[k] == results[0], k
+
+
 @pytest.mark.parametrize("name,dna_name,kw", [
     ("demo_lg40.TFOsorted", "testDNA.fa", dict(cLength=40)),
     ("demo_default.TFOsorted", "testDNA.fa", dict()),
