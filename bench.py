@@ -321,6 +321,7 @@ def main():
         kms = agg["kernel_ms"]
         ik, il = iso["kernel_ms"], iso["kernel_launches"]
         n_avg = iso["cells_stage2"] / max(1, iso["units"]) / m        # mean segment length of the isolated pass
+        fwd_cells = max(0, iso["cells_stage3"] - iso["band_cells"])   # executed by k_align_fwd (+ the few cells of the finish kernels)
 
         def kernel_roofline(idx):
             """HBM roofline of one of the two DP kernels from the isolated pass: algorithmic bytes per launch / exclusive
@@ -331,11 +332,11 @@ def main():
                 items = iso["units"] + iso["stage1_word_reruns"]
                 per_item = 3 * n_avg + 5 * m
                 alt = {"algorithmic_bytes_per_launch_3n_only": int(3 * n_avg * items / launches_k)}
-            else:          # k_align_fwd, per window try: L + 2 stream bytes in, 16-byte descriptor in, 24-byte result out
-                calls = max(1, iso["align_calls"])
-                items = calls + iso["align_word_reruns"]
-                per_item = iso["cells_stage3"] / m / calls + 2 + 16 + 24
-                alt = {}
+            else:          # k_align_fwd, per full-height pass: L + 2 stream bytes in, 16-byte descriptor in, 24-byte result out
+                # full-height passes = reverse passes (bounds for the band kernel) + the tries no band proved + 16-bit re-runs
+                items = max(1, iso["rev_bound_passes"] + (iso["align_calls"] - iso["band_proven"]) + iso["align_word_reruns"])
+                per_item = fwd_cells / m / items + 2 + 16 + 24
+                alt = {"full_height_passes": int(items), "of_them_reverse_passes": int(iso["rev_bound_passes"])}
             alg = per_item * items / launches_k
             # measured HBM bytes per launch: bytes per item from the committed counter passes (two separate rocprofv3 --pmc runs folded
             # by tools/pmc_traffic.py; FETCH doubled for gfx950 as the guide prescribes) x the items of one launch
@@ -343,7 +344,8 @@ def main():
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
                 per = pmc["k_scan" if idx == 0 else "k_align_fwd"]["hbm_bytes_per_item"]
-                traffic = int(per * items / launches_k)
+                # (the counter file divides k_align_fwd's bytes by ALL window tries of its run, so the same denominator is used here)
+                traffic = int(per * (items if idx == 0 else iso["align_calls"]) / launches_k)
                 tnote = (f"profiles/{PMC_FILE}: {per:.0f} B per {'unit' if idx == 0 else 'window try'} (FETCH_SIZE x 2 + WRITE_SIZE of separate "
                          "rocprofv3 --pmc passes, tools/pmc_traffic.py) x the items of one launch of this run")
             except (OSError, KeyError, ValueError):
@@ -403,7 +405,8 @@ def main():
             "roofline": kernel_roofline(0),
             "roofline_stage3": kernel_roofline(2),
             "valu": valu(0, "k_scan", iso["cells_stage2"]),
-            "valu_stage3": valu(2, "k_align_fwd", iso["cells_stage3"]),
+            "valu_stage3": valu(2, "k_align_fwd", fwd_cells),
+            "valu_band": valu(8, "k_align_fwd", iso["band_cells"]) if ik[8] > 0 else None,
             "valu_note": "useful row work = packed 16-bit VALU instructions per DP cell x executed cells / EXCLUSIVE HIP-event time "
                          "(isolated pass); peak = the measured sustained issue rate of a pure stream of packed 16-bit ops on this chip at "
                          "the kernel's occupancy: 1024 SIMDs x 64 lanes / 1.81 ns (tools/valu_issue_bench.hip, "
