@@ -83,7 +83,7 @@ class _Result(C.Structure):
                 ("stats", ScanStats)]
 
 
-EXPORTS = ["fasim_params_default", "fasim_engine_create", "fasim_engine_destroy", "fasim_last_error", "fasim_set_option", "fasim_set_query",
+EXPORTS = ["fasim_params_default", "fasim_engine_create", "fasim_engine_create_ex", "fasim_engine_destroy", "fasim_last_error", "fasim_set_option", "fasim_set_query",
            "fasim_calc_score_once", "fasim_ssw_pre_align", "fasim_ssw_colmax_word", "fasim_pick_candidates", "fasim_ssw_align", "fasim_pre_align_batch",
            "fasim_align_batch", "fasim_encode_unit", "fasim_sim_forward_batch", "fasim_sim_finish_unit", "fasim_scan", "fasim_scan_queries", "fasim_merge_results", "fasim_rebase_offsets", "fasim_load_dna", "fasim_result_free", "fasim_segment_count",
            "fasim_tfosorted", "fasim_tfoclass", "fasim_tfosorted_ex", "fasim_tfoclass_ex", "fasim_tail_outputs", "fasim_upper_case", "fasim_free",

@@ -1310,20 +1310,23 @@ void fasim_params_default(fasim_params* p)
 
 const char* fasim_last_error(const fasim_engine* e) { return e ? e->err.c_str() : g_last_error.c_str(); }
 
-int fasim_engine_create(int device, fasim_engine** out)
+int fasim_engine_create(int device, fasim_engine** out) { return fasim_engine_create_ex(device, 0, out); }
+
+int fasim_engine_create_ex(int device, int32_t flags, fasim_engine** out)
 {
 	if (!out) return fail(nullptr, FASIM_E_ARG, "null out pointer");
 	*out = nullptr;
+	const bool tune = !(flags & FASIM_CREATE_NO_PROCESS_TUNING);
 	// fasim_scan keeps ~10 batches in flight on as many streams; the HIP runtime multiplexes streams onto 4 hardware
 	// queues unless told otherwise, which serialises unrelated batches.  Only effective before the runtime initialises
 	// (a host application that touches HIP earlier should export GPU_MAX_HW_QUEUES itself).
-	setenv("GPU_MAX_HW_QUEUES", "8", 0);
+	if (tune) setenv("GPU_MAX_HW_QUEUES", "8", 0);
 	// Host allocator: every batch builds and drops tables of a few MB on its host threads.  glibc hands such blocks back to the
 	// kernel (munmap / heap trimming), and while the address space of a process with live HIP queues changes, the driver's MMU
 	// notifier holds those queues up (a 120 ms kernel that overlaps the freeing of half a million strings takes 190-250 ms:
 	// tools/iso_probe.py).  Keeping freed blocks of up to 32 MB in the heap removes most of that: 2.42 -> 2.38 s per 50 Mb scan
 	// (profiles/r02_ab_malloc.txt).  Process-wide settings; FASIM_MALLOPT=0 leaves the allocator alone.
-	{
+	if (tune) {
 		static const bool once = [] {
 			const char* e = getenv("FASIM_MALLOPT");
 			if (e && atoi(e) == 0) return false;
@@ -1345,7 +1348,7 @@ int fasim_engine_create(int device, fasim_engine** out)
 		// application that touches HIP first (PyTorch) has to set it itself (bench.py does).  An event created with
 		// hipEventBlockingSync does not have this effect on ROCm 7.2.  FASIM_BLOCKING_SYNC=0 leaves the polling wait.
 		const char* e = getenv("FASIM_BLOCKING_SYNC");
-		if (!(e && atoi(e) == 0)) { (void)hipSetDevice(device); (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); (void)hipGetLastError(); }
+		if (tune && !(e && atoi(e) == 0)) { (void)hipSetDevice(device); (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); (void)hipGetLastError(); }
 	}
 	fasim_engine* E = new fasim_engine();
 	E->device = device;

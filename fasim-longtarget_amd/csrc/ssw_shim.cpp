@@ -37,7 +37,8 @@ fasim_engine* engine_locked()
 {
 	if (g_engine) return g_engine;
 	const char* d = getenv("FASIM_DEVICE");
-	if (fasim_engine_create(d ? atoi(d) : 0, &g_engine) != FASIM_OK) {
+	// (a drop-in inside somebody else's process: no mallopt, no device flags, no environment changes)
+	if (fasim_engine_create_ex(d ? atoi(d) : 0, FASIM_CREATE_NO_PROCESS_TUNING, &g_engine) != FASIM_OK) {
 		fprintf(stderr, "ssw (fasim HIP shim): %s\n", fasim_last_error(nullptr));
 		g_engine = nullptr;
 	}

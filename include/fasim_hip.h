@@ -55,6 +55,11 @@ void fasim_params_default(fasim_params* p);
  *   mallopt(): freed host blocks of up to 32 MB stay in the heap instead of being unmapped -- unmapping host memory while HIP
  *     queues are live stalls the running kernels (FASIM_MALLOPT=0). */
 int  fasim_engine_create(int device, fasim_engine** out);
+/* flags = FASIM_CREATE_NO_PROCESS_TUNING: none of the three process-wide settings above is touched (what a host application that
+ * only embeds single calls wants; the `ssw.h` symbols create their engine this way).  The worker engines of a scan inherit nothing:
+ * they are created by the scan through fasim_engine_create, so a throughput run should create its engine without the flag. */
+#define FASIM_CREATE_NO_PROCESS_TUNING 1
+int  fasim_engine_create_ex(int device, int32_t flags, fasim_engine** out);
 void fasim_engine_destroy(fasim_engine* e);
 const char* fasim_last_error(const fasim_engine* e);   /* e may be NULL: last global error */
 
