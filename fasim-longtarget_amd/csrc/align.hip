@@ -148,9 +148,12 @@ __device__ __forceinline__ int fwd_cell_score(const FwdArgs& a, int t, int v, in
 // on every SIMD; with 256-thread workgroups LDS allowed only three (3 waves per SIMD), and the packed VALU ops issue ~15 %
 // slower at 3 waves per SIMD than at 4 (profiles/r02_valu_issue_bench.txt)
 constexpr int FWD_THREADS = 512;
-template <int RP, bool TAINT>
+// REV (plain variant only): the reverse pass.  It wants the lane maxima per zone and nothing else, so the row tags of the keys,
+// the key hand-over between lanes and the whole pipe end are left out (about 35 of 380 instructions per step).
+template <int RP, bool TAINT, bool REV = false>
 __global__ void __launch_bounds__(FWD_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) k_align_fwd(FwdArgs a)
 {
+	static_assert(!(TAINT && REV), "the reverse pass is a plain pass");
 	constexpr int SC = TAINT ? 2 * AL_SCALE : AL_SCALE;      // value scale; TAINT: bit 5 = taint, bits 0..4 = row tag
 	extern __shared__ __align__(16) uint8_t prof[];
 	const int lane = threadIdx.x & 63;
@@ -277,7 +280,7 @@ __global__ void __launch_bounds__(FWD_THREADS) __attribute__((amdgpu_waves_per_e
 				const v2u ho = __builtin_elementwise_sub_sat(a_u(h), gapo);
 				E[r] = a_i(__builtin_elementwise_max(__builtin_elementwise_sub_sat(u_from(E[r]), dec), ho));
 				const v2u fnew = __builtin_elementwise_max(__builtin_elementwise_sub_sat(f, dec), ho);
-				const v2s key = h | (v2s){ (short)(31 - r), (short)(31 - r) };
+				const v2s key = REV ? h : (h | (v2s){ (short)(31 - r), (short)(31 - r) });
 				if (r == RP - 1) {
 					f = (fnew & actm) | (f & ~actm);
 					lkx[r & 3] = __builtin_elementwise_max(lkx[r & 3], a_s(a_u(key) & actm));
@@ -292,8 +295,8 @@ __global__ void __launch_bounds__(FWD_THREADS) __attribute__((amdgpu_waves_per_e
 			const v2s lkey = __builtin_elementwise_max(__builtin_elementwise_max(lkx[0], lkx[1]), __builtin_elementwise_max(lkx[2], lkx[3]));
 			asm volatile("" :: "v"(a_i(lkey)));      // pin the reduction before the hazard branch (see scan.hip)
 			fbot = a_i(f);
-			if constexpr (!TAINT) {
-				if (a.lane_ub) {
+			if constexpr (REV) {
+				{
 					// reverse pass: my two columns' maxima (value = key >> 5) go into the running maxima of the zones that hold the column
 					const v2u tcu = u_from(tc);
 					const v2u zz = (tcu >> (v2u){ 5, 5 }) & (v2u){ 3, 3 };
@@ -374,6 +377,15 @@ __global__ void __launch_bounds__(FWD_THREADS) __attribute__((amdgpu_waves_per_e
 					tc |= a_i(__builtin_elementwise_min(hz_b, (v2u){ 1, 1 }) << (v2u){ 4, 4 });
 				}
 			}
+			if constexpr (REV) {
+				// (no result per window: only the hand-over of the tile's bottom row to the next tile)
+				if (!last_tile) {
+					const int pos = step - 127;
+					if (lane == 63 && pos >= 0 && pos < slen)
+						bnd[pos] = make_uint4(((uint32_t)hbot >> 16) | ((uint32_t)fbot & 0xffff0000u), ((uint32_t)tc & 0xffff0000u), 0u, 0u);
+				}
+				continue;
+			}
 			// per-column (max, smallest row) keys
 			const uint32_t lk = (uint32_t)a_i(lkey);
 			const uint32_t loc_lo = (((lk & 0xFFFFu) >> 5) << 16) | (uint32_t)(kbase_lo + (int)(lk & 31u));
@@ -406,7 +418,7 @@ __global__ void __launch_bounds__(FWD_THREADS) __attribute__((amdgpu_waves_per_e
 					}
 					cidx++;
 					if (tag & TAG_LAST) {
-						if (lane == 0 && !(!TAINT && a.lane_ub)) {
+						if (lane == 0) {
 							FwdOut o;
 							o.score = runmax; o.ref_end = end_ref; o.read_end = end_read < a.m - 1 ? end_read : a.m - 1;
 							o.flags = hzflag | wtaint; o.ref_begin = 0; o.read_begin = 0;
@@ -420,7 +432,7 @@ __global__ void __launch_bounds__(FWD_THREADS) __attribute__((amdgpu_waves_per_e
 	}
 }
 
-template <int RP, bool TAINT>
+template <int RP, bool TAINT, bool REV = false>
 static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st)
 {
 	hipError_t err = hipMemsetAsync(a.counter, 0, sizeof(uint32_t), st);
@@ -429,7 +441,7 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st)
 	constexpr int WPB = FWD_THREADS / 64;
 	long blocks = ((long)a.ntask + WPB - 1) / WPB;
 	if (blocks > 256 * 2) blocks = 256 * 2;
-	hipLaunchKernelGGL((k_align_fwd<RP, TAINT>), dim3((unsigned)blocks), dim3(FWD_THREADS), (size_t)6 * AL_CODE_STRIDE, st, a);
+	hipLaunchKernelGGL((k_align_fwd<RP, TAINT, REV>), dim3((unsigned)blocks), dim3(FWD_THREADS), (size_t)6 * AL_CODE_STRIDE, st, a);
 	return hipGetLastError();
 }
 
@@ -448,7 +460,7 @@ hipError_t launch_align_fwd(const FwdLaunch& L, hipStream_t st)
 		a.tile = t;
 		hipError_t err = hipErrorInvalidValue;
 		switch (rp) {
-#define FASIM_FWD_CASE(N) case N: err = L.word ? launch_fwd_t<N, false>(a, st) : launch_fwd_t<N, true>(a, st); break;
+#define FASIM_FWD_CASE(N) case N: err = a.lane_ub ? launch_fwd_t<N, false, true>(a, st) : (L.word ? launch_fwd_t<N, false>(a, st) : launch_fwd_t<N, true>(a, st)); break;
 		FASIM_FWD_CASE(1) FASIM_FWD_CASE(2) FASIM_FWD_CASE(3) FASIM_FWD_CASE(4) FASIM_FWD_CASE(5) FASIM_FWD_CASE(6)
 		FASIM_FWD_CASE(7) FASIM_FWD_CASE(8) FASIM_FWD_CASE(9) FASIM_FWD_CASE(10) FASIM_FWD_CASE(11) FASIM_FWD_CASE(12)
 		FASIM_FWD_CASE(13) FASIM_FWD_CASE(14) FASIM_FWD_CASE(15) FASIM_FWD_CASE(16) FASIM_FWD_CASE(17) FASIM_FWD_CASE(18)
