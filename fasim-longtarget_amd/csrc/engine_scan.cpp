@@ -1,0 +1,534 @@
+// fasim-longtarget_amd/csrc/engine_scan.cpp -- batches and workers: scan_batch (segments -> units -> stages 1+2 of one batch), the
+// forward sweep of -F, result packing, and scan_core (work queue of (lncRNA, batch) items over the worker engines).
+#include "engine.h"
+
+// ---- row f3: forward sweep of classic SIM ---------------------------------------------------------------------
+// addnode() (sim.h:99-148) over the events of one unit in row-major order: a known start point is updated (strictly larger
+// score moves the end point; the bounding box grows), a new one is appended or, with K nodes present, overwrites the first
+// node of lowest score whatever its own score is.
+// Forward sweep + node list (k_sim_forward: the list is kept and replayed inside the wave, sim.hip) for units
+// [first, first + nrun) of a resident code buffer.  min_scores[u] belongs to unit first + u.  lists[u] receives the node list.
+// Units run in slices of <= 1024 (64 row segments of one unit's length each = 5 MB of scratch per unit); *ready (if given) is
+// the number of leading units whose lists are complete, so that the host half can start on a slice while the next one runs.
+// `lists` must have been sized to nrun by the caller.
+int sim_forward_units(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, const int32_t* unit_len_dev, const int32_t* unit_len_host,
+	int first, int nrun, const int64_t* min_scores, std::atomic<int>* ready, std::vector<std::vector<fasim_sim_node>>& lists)
+{
+	static_assert(sizeof(SimNodeDev) == sizeof(fasim_sim_node) && SIM_K == FASIM_SIM_K, "node layout");
+	if (nrun <= 0) return FASIM_OK;
+	int maxlen = 1;
+	for (int u = 0; u < nrun; u++) maxlen = std::max(maxlen, unit_len_host[first + u]);
+	if (E->m > 65535 || maxlen > 65535) return fail(E, FASIM_E_UNSUPPORTED, "the SIM forward sweep holds start points in 16 bits: query %d / target %d nt is too long", E->m, maxlen);
+	const int64_t row_stride = (maxlen + 2 + 15) & ~15;
+	const uint32_t cap = (uint32_t)((maxlen + 15) & ~15);
+	DevBuf& d_min = E->sim_min; DevBuf& d_row = E->sim_row; DevBuf& d_ev = E->sim_ev; DevBuf& d_cnt = E->sim_cnt; DevBuf& d_nodes = E->sim_nodes;
+	int rc = upload(E, d_min, min_scores, sizeof(int64_t) * nrun); if (rc) return rc;
+	const int per_slice = 1024;         // waves in flight: the sweep of one unit takes ~1.5 s of one wave, the chip holds thousands
+	std::vector<fasim_sim_node> hn((size_t)per_slice * FASIM_SIM_K);
+	std::vector<int32_t> hc((size_t)per_slice);
+	for (int u0 = 0; u0 < nrun; u0 += per_slice) {
+		const int cnt = std::min(per_slice, nrun - u0);
+		HIPOK(d_ev.ensure((size_t)cnt * 64 * cap * sizeof(SimEvent)));
+		HIPOK(d_row.ensure((size_t)cnt * 2 * row_stride * sizeof(uint64_t)));
+		HIPOK(d_cnt.ensure(sizeof(int32_t) * cnt));
+		HIPOK(d_nodes.ensure(sizeof(SimNodeDev) * (size_t)cnt * SIM_K));
+		SimFwdArgs a;
+		a.tcodes = tcodes_dev + (size_t)(first + u0) * tstride; a.unit_len = unit_len_dev + first + u0; a.tstride = tstride;
+		a.qcodes = E->qsim.as<uint8_t>(); a.m = E->m; a.min_score = d_min.as<int64_t>() + u0;
+		a.rowbuf = d_row.as<uint64_t>(); a.row_stride = row_stride;
+		a.events = d_ev.as<SimEvent>(); a.event_cap = cap; a.nodes = d_nodes.as<SimNodeDev>(); a.node_count = d_cnt.as<int32_t>();
+		hipError_t he;
+		{ TimedScope ts(E, 7); he = launch_sim_forward(a, cnt, E->st); }
+		if (he != hipSuccess) return fail(E, FASIM_E_HIP, "sim_forward launch failed: %s", hipGetErrorString(he));
+		HIPOK(hipMemcpyAsync(hc.data(), d_cnt.p, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, E->st));
+		HIPOK(hipMemcpyAsync(hn.data(), d_nodes.p, sizeof(fasim_sim_node) * (size_t)cnt * FASIM_SIM_K, hipMemcpyDeviceToHost, E->st));
+		HIPOK(hipStreamSynchronize(E->st));
+		for (int k = 0; k < cnt; k++) {
+			if (hc[(size_t)k] < 0 || hc[(size_t)k] > FASIM_SIM_K) return fail(E, FASIM_E_HIP, "sim_forward: bad node count");
+			lists[(size_t)(u0 + k)].assign(hn.begin() + (size_t)k * FASIM_SIM_K, hn.begin() + (size_t)k * FASIM_SIM_K + hc[(size_t)k]);
+		}
+		if (ready) ready->store(u0 + cnt, std::memory_order_release);
+	}
+	return FASIM_OK;
+}
+
+
+
+int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t* dna_dev, int64_t shard_lo, int64_t b0, int64_t b1,
+	const fasim_params& p, const std::vector<int>& encs, int tstride, BatchCtx& C, fasim_scan_stats& st)
+{
+	int rc = FASIM_OK;
+	const int64_t step = p.cutLength - p.overlapLength;
+	const int nenc = (int)encs.size();
+	C.B = UnitBatch(); C.tstride = tstride; C.nenc = nenc; C.nseg = 0; C.step = step; C.dna = dna; C.p = &p; C.encs = &encs; C.stage3_done = false;
+	C.per_unit.clear();
+	{
+		// segments of this batch that are not skipped by same_seq()
+		std::vector<int32_t>& sstart = C.sstart; std::vector<int32_t>& slen = C.slen; std::vector<int64_t>& sidx = C.sidx;
+		sstart.clear(); slen.clear(); sidx.clear();
+		if (!dna_dev) {
+			// Streaming ingest: the record is in host memory only.  The slice this batch needs goes through the worker's
+			// pinned staging buffer and its own stream; with ~10 batches in flight the copy of one batch overlaps the kernels
+			// of the others, and HBM holds 10 slices of ~2.5 MB instead of the whole record.
+			const int64_t lo = b0 * step, hi = std::min<int64_t>(dna_len, (b1 - 1) * step + p.cutLength);
+			const size_t bytes = (size_t)(hi - lo);
+			if (bytes > E->pin_cap) {
+				if (E->pin_dna) { (void)hipHostFree(E->pin_dna); E->pin_dna = nullptr; E->pin_cap = 0; }
+				HIPOK(hipHostMalloc(&E->pin_dna, bytes + bytes / 8, hipHostMallocDefault));
+				E->pin_cap = bytes + bytes / 8;
+			}
+			memcpy(E->pin_dna, dna + lo, bytes);
+			HIPOK(E->dna.ensure(bytes));
+			HIPOK(hipMemcpyAsync(E->dna.p, E->pin_dna, bytes, hipMemcpyHostToDevice, E->st));
+			dna_dev = E->dna.as<uint8_t>(); shard_lo = lo;
+		}
+		for (int64_t s = b0; s < b1; s++) {
+			const int64_t pos = s * step;
+			const int len = (int)std::min<int64_t>(p.cutLength, dna_len - pos);
+			st.segments++;
+			if (same_seq(dna + pos, len)) { st.segments_skipped++; continue; }
+			sstart.push_back((int32_t)(pos - shard_lo)); slen.push_back(len); sidx.push_back(s);
+			st.logical_cells += (int64_t)E->m * len * nenc;
+		}
+		const int nseg = (int)sidx.size();
+		if (!nseg) return FASIM_OK;
+		C.nseg = nseg;
+		UnitBatch& B = C.B; B.nunit = nseg * nenc; B.tstride = tstride; B.unit_len.resize(B.nunit);
+		for (int s = 0; s < nseg; s++) for (int k = 0; k < nenc; k++) B.unit_len[s * nenc + k] = slen[s];
+		st.units += B.nunit;
+		// executed DP cells: the fused k_scan pass serves stage 1 AND stage 2, so it is counted once (as stage 2); stage 1 is
+		// counted only where it really is a pass of its own (units with N / non-ACGT queries, the striped fallback)
+		for (int s = 0; s < nseg; s++) st.cells_stage2 += (int64_t)E->m * slen[s] * nenc;
+		rc = upload(E, E->seg_start, sstart.data(), sizeof(int32_t) * nseg); if (rc) return rc;
+		rc = upload(E, E->seg_len, slen.data(), sizeof(int32_t) * nseg); if (rc) return rc;
+		rc = upload(E, E->unit_len, B.unit_len.data(), sizeof(int32_t) * B.nunit); if (rc) return rc;
+		HIPOK(E->tcodes.ensure((size_t)B.nunit * tstride));
+		hipError_t he;
+		{ TimedScope ts(E, 4);
+		he = launch_encode(dna_dev, E->seg_start.as<int32_t>(), E->seg_len.as<int32_t>(), nseg,
+			E->enc_ids.as<int32_t>(), nenc, E->enc_lut.as<uint8_t>(), E->tcodes.as<uint8_t>(), tstride, E->st); }
+		if (he != hipSuccess) return fail(E, FASIM_E_HIP, "encode launch failed: %s", hipGetErrorString(he));
+
+		// ---- stages 1+2: fused systolic scan (scan.hip); stripe-faithful kernels for hazard units, for
+		//      queries beyond 3072 rows, or when FASIM_SCAN_V1=1
+		double t0 = now_s();
+		std::vector<int32_t>& hoff = C.hoff; std::vector<int32_t>& hcnt = C.hcnt; std::vector<int32_t>& thr = C.thr;
+		std::vector<uint32_t>& hits = C.hits;
+		hoff.clear(); hcnt.clear(); thr.clear(); hits.clear();
+		bool done_v2 = false;
+		if (!E->scan_v1) {
+			std::vector<char> need1(B.nunit, E->query_acgt ? 0 : 1);
+			if (E->query_acgt) {
+				for (int s = 0; s < nseg; s++) {
+					const char* sg = dna + sidx[s] * step; bool clean = true;
+					for (int i = 0; i < slen[s]; i++) { const char c = sg[i]; if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T')) { clean = false; break; } }
+					if (!clean) for (int k = 0; k < nenc; k++) need1[s * nenc + k] = 1;
+				}
+			}
+			ScanOut so;
+			rc = run_scan_v2(E, B, need1, so, &st);
+			if (rc < 0) return rc;
+			if (rc == 0) { hoff.swap(so.hit_off); hcnt.swap(so.hit_cnt); thr.swap(so.thr); hits.swap(so.hits); done_v2 = true; }
+		}
+		st.t_stage2_s += now_s() - t0;
+		if (!done_v2) {
+		// ---- stage 1
+		t0 = now_s();
+		std::vector<int> s1;
+		for (int u = 0; u < B.nunit; u++) st.cells_stage1 += (int64_t)E->m * B.unit_len[u];
+		rc = run_stage1(E, B, s1, &st.stage1_word_reruns); if (rc) return rc;
+		st.t_stage1_s += now_s() - t0;
+
+		// ---- stage 2 + hits
+		t0 = now_s();
+		rc = run_stage2(E, B); if (rc) return rc;
+		rc = upload(E, E->stage1, s1.data(), sizeof(int32_t) * B.nunit); if (rc) return rc;
+		HIPOK(E->hit_off.ensure(sizeof(int32_t) * B.nunit)); HIPOK(E->hit_cnt.ensure(sizeof(int32_t) * B.nunit));
+		HIPOK(E->thr.ensure(sizeof(int32_t) * B.nunit)); HIPOK(E->hits_total.ensure(64));
+		hoff.resize(B.nunit); hcnt.resize(B.nunit); thr.resize(B.nunit);
+		std::vector<int32_t> pre_max(B.nunit);
+		size_t hits_cap = std::max<size_t>(E->hits.cap / 4, (size_t)B.nunit * 128);
+		for (;;) {
+			HIPOK(E->hits.ensure(hits_cap * sizeof(uint32_t)));
+			{ TimedScope ts(E, 4);
+			he = launch_hits(E->colmax.as<uint8_t>(), nullptr, E->unit_len.as<int32_t>(), E->stage1.as<int32_t>(), B.nunit, tstride,
+				E->hits.as<uint32_t>(), (uint32_t)hits_cap, E->hits_total.as<uint32_t>(), E->hit_off.as<int32_t>(),
+				E->hit_cnt.as<int32_t>(), E->thr.as<int32_t>(), E->st); }
+			if (he != hipSuccess) return fail(E, FASIM_E_HIP, "hits launch failed: %s", hipGetErrorString(he));
+			uint32_t total = 0;
+			HIPOK(hipMemcpyAsync(&total, E->hits_total.p, sizeof total, hipMemcpyDeviceToHost, E->st));
+			HIPOK(hipStreamSynchronize(E->st));
+			if (total <= hits_cap) { hits.resize(total); break; }
+			hits_cap = (size_t)total + 1024;
+		}
+		HIPOK(hipMemcpyAsync(hoff.data(), E->hit_off.p, sizeof(int32_t) * B.nunit, hipMemcpyDeviceToHost, E->st));
+		HIPOK(hipMemcpyAsync(hcnt.data(), E->hit_cnt.p, sizeof(int32_t) * B.nunit, hipMemcpyDeviceToHost, E->st));
+		HIPOK(hipMemcpyAsync(thr.data(), E->thr.p, sizeof(int32_t) * B.nunit, hipMemcpyDeviceToHost, E->st));
+		HIPOK(hipMemcpyAsync(pre_max.data(), E->max_out.p, sizeof(int32_t) * B.nunit, hipMemcpyDeviceToHost, E->st));
+		if (!hits.empty()) HIPOK(hipMemcpyAsync(hits.data(), E->hits.p, sizeof(uint32_t) * hits.size(), hipMemcpyDeviceToHost, E->st));
+		HIPOK(hipStreamSynchronize(E->st));
+		for (int u = 0; u < B.nunit; u++) if (pre_max[u] == 255) st.stage2_overflow_units++;
+		st.t_stage2_s += now_s() - t0;
+		}
+
+		if (p.classicSim) {
+			// ---- -F: classic SIM instead of fastSIM (Fasim-LongTarget.cpp:420-426): the forward sweep of every unit on the GPU
+			//      (k_sim_forward + node-list replay), traceback / re-sweeps / triplex records on the host threads (host_sim.cpp)
+			t0 = now_s();
+			std::vector<int64_t> mins((size_t)B.nunit);
+			for (int u = 0; u < B.nunit; u++) mins[(size_t)u] = thr[(size_t)u];
+			std::vector<std::vector<fasim_sim_node>> lists((size_t)B.nunit);
+			std::vector<std::vector<HostTriplex>>& per_unit = C.per_unit;
+			per_unit.assign((size_t)B.nunit, std::vector<HostTriplex>());
+			// the host threads finish the units of a slice while the GPU sweeps the next one
+			std::atomic<int> next(0), ready(0);
+			std::atomic<bool> abort(false);
+			auto work = [&]() {
+				std::string target, src;
+				for (;;) {
+					const int u = next.fetch_add(1);
+					if (u >= B.nunit) break;
+					while (u >= ready.load(std::memory_order_acquire) && !abort.load()) std::this_thread::sleep_for(std::chrono::microseconds(200));
+					if (abort.load()) break;
+					const int s = u / nenc, enc = encs[(size_t)(u % nenc)];
+					encode_unit_host(dna + sidx[(size_t)s] * step, slen[(size_t)s], enc, target, src);
+					sim_finish_unit(E->rna, target, src, (long)(sidx[(size_t)s] * step), thr[(size_t)u], enc, p, lists[(size_t)u], per_unit[(size_t)u]);
+					for (HostTriplex& t : per_unit[(size_t)u]) { t.seg = (int)sidx[(size_t)s]; t.enc = enc; }
+				}
+			};
+			const int nt = std::max(1, std::min(E->sim_threads, B.nunit));
+			std::vector<std::thread> th;
+			for (int k = 0; k < nt; k++) th.emplace_back(work);
+			rc = sim_forward_units(E, E->tcodes.as<uint8_t>(), tstride, E->unit_len.as<int32_t>(), B.unit_len.data(), 0, B.nunit, mins.data(), &ready, lists);
+			if (rc) abort.store(true);
+			for (auto& t : th) t.join();
+			if (rc) return rc;
+			st.t_stage3_s += now_s() - t0;
+			C.stage3_done = true;
+			return FASIM_OK;
+		}
+		// the scan phase ends here: stage 3 runs per unit range (stage3_range), on this engine or on helpers
+		C.per_unit.assign((size_t)B.nunit, std::vector<HostTriplex>());
+		C.seg_acgtn.resize((size_t)nseg);
+		for (int s = 0; s < nseg; s++) C.seg_acgtn[(size_t)s] = only_acgtn(dna + sidx[(size_t)s] * step, slen[(size_t)s]) ? 1 : 0;
+	}
+	return FASIM_OK;
+}
+
+
+// LongTarget()'s tail filter (Fasim-LongTarget.cpp:589-597) over the units of a finished batch, in canonical order
+static void collect_batch(BatchCtx& C, std::vector<HostTriplex>& all)
+{
+	const fasim_params& p = *C.p;
+	for (auto& unit : C.per_unit)
+		for (HostTriplex& t : unit)
+			if (t.score >= p.scoreMin && t.identity >= p.minIdentity && t.tri_score >= p.minStability && t.nt >= p.cLength)
+				all.push_back(std::move(t));
+}
+
+// pack the records of one query into the C result
+int pack_result(fasim_engine* E, std::vector<HostTriplex>& all, const fasim_scan_stats& st, fasim_result** out)
+{
+	fasim_result* R = (fasim_result*)calloc(1, sizeof(fasim_result));
+	if (!R) return fail(E, FASIM_E_NOMEM, "out of memory");
+	size_t pool = 0;
+	for (const HostTriplex& t : all) pool += t.tfo.size() + t.tts.size() + 2;
+	R->count = (int64_t)all.size();
+	R->recs = (fasim_triplex*)calloc(std::max<size_t>(1, all.size()), sizeof(fasim_triplex));
+	R->pool = (char*)calloc(std::max<size_t>(1, pool), 1);
+	if (!R->recs || !R->pool) { fasim_result_free(R); return fail(E, FASIM_E_NOMEM, "out of memory"); }
+	R->pool_len = (int64_t)pool;
+	size_t off = 0;
+	for (size_t i = 0; i < all.size(); i++) {
+		const HostTriplex& t = all[i];
+		fasim_triplex& r = R->recs[i];
+		r.stari = t.stari; r.endi = t.endi; r.starj = t.starj; r.endj = t.endj; r.strand = t.strand; r.reverse = t.reverse;
+		r.rule = t.rule; r.nt = t.nt; r.score = t.score; r.identity = t.identity; r.tri_score = t.tri_score; r.seg = t.seg; r.enc = t.enc;
+		r.tfo_off = (int64_t)off; memcpy(R->pool + off, t.tfo.c_str(), t.tfo.size() + 1); off += t.tfo.size() + 1;
+		r.tts_off = (int64_t)off; memcpy(R->pool + off, t.tts.c_str(), t.tts.size() + 1); off += t.tts.size() + 1;
+	}
+	R->stats = st;
+	*out = R;
+	return FASIM_OK;
+}
+
+// The same from the batches' lists as they are (one query's batches in canonical order): record and pool positions of every
+// batch follow from a prefix sum, so the batches are copied side by side on `threads` host threads.
+static int pack_result_parts(fasim_engine* E, const std::vector<const std::vector<HostTriplex>*>& parts, const fasim_scan_stats& st, int threads,
+	fasim_result** out)
+{
+	fasim_result* R = (fasim_result*)calloc(1, sizeof(fasim_result));
+	if (!R) return fail(E, FASIM_E_NOMEM, "out of memory");
+	const size_t np = parts.size();
+	std::vector<size_t> rbase(np + 1, 0), pbase(np + 1, 0);
+	for (size_t k = 0; k < np; k++) {
+		size_t pool = 0;
+		for (const HostTriplex& t : *parts[k]) pool += t.tfo.size() + t.tts.size() + 2;
+		rbase[k + 1] = rbase[k] + parts[k]->size(); pbase[k + 1] = pbase[k] + pool;
+	}
+	const size_t count = rbase[np], pool = pbase[np];
+	R->count = (int64_t)count;
+	R->recs = (fasim_triplex*)malloc(std::max<size_t>(1, count) * sizeof(fasim_triplex));
+	R->pool = (char*)malloc(std::max<size_t>(1, pool));
+	if (!R->recs || !R->pool) { fasim_result_free(R); return fail(E, FASIM_E_NOMEM, "out of memory"); }
+	R->pool_len = (int64_t)pool;
+	if (!pool) R->pool[0] = 0;
+	std::atomic<size_t> next(0);
+	auto work = [&]() {
+		for (;;) {
+			const size_t k = next.fetch_add(1);
+			if (k >= np) break;
+			size_t off = pbase[k];
+			fasim_triplex* dst = R->recs + rbase[k];
+			for (const HostTriplex& t : *parts[k]) {
+				fasim_triplex r;
+				memset(&r, 0, sizeof r);
+				r.stari = t.stari; r.endi = t.endi; r.starj = t.starj; r.endj = t.endj; r.strand = t.strand; r.reverse = t.reverse;
+				r.rule = t.rule; r.nt = t.nt; r.score = t.score; r.identity = t.identity; r.tri_score = t.tri_score; r.seg = t.seg; r.enc = t.enc;
+				r.tfo_off = (int64_t)off; memcpy(R->pool + off, t.tfo.c_str(), t.tfo.size() + 1); off += t.tfo.size() + 1;
+				r.tts_off = (int64_t)off; memcpy(R->pool + off, t.tts.c_str(), t.tts.size() + 1); off += t.tts.size() + 1;
+				*dst++ = r;
+			}
+		}
+	};
+	const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, threads), count > 20000 ? np : 1));
+	if (nt == 1) work();
+	else { std::vector<std::thread> th; for (int k = 0; k < nt; k++) th.emplace_back(work); for (auto& t : th) t.join(); }
+	R->stats = st;
+	*out = R;
+	return FASIM_OK;
+}
+
+static void add_stats(fasim_scan_stats& st, const fasim_scan_stats& x)
+{
+	st.segments += x.segments; st.segments_skipped += x.segments_skipped; st.units += x.units; st.candidates += x.candidates;
+	st.align_calls += x.align_calls; st.align_word_reruns += x.align_word_reruns; st.stage2_overflow_units += x.stage2_overflow_units;
+	st.stage1_word_reruns += x.stage1_word_reruns; st.logical_cells += x.logical_cells; st.t_stage1_s += x.t_stage1_s;
+	st.t_stage2_s += x.t_stage2_s; st.t_stage3_s += x.t_stage3_s; st.t_host_s += x.t_host_s; st.cells_stage1 += x.cells_stage1;
+	st.cells_stage2 += x.cells_stage2; st.cells_stage3 += x.cells_stage3; st.hazard_units += x.hazard_units; st.rev_exact += x.rev_exact;
+	st.exact_replays += x.exact_replays; st.tries_skipped += x.tries_skipped;
+	st.band_tries += x.band_tries; st.band_proven += x.band_proven; st.band_cells += x.band_cells; st.rev_bound_passes += x.rev_bound_passes;
+	for (int k = 0; k < FASIM_KERNEL_FAMILIES; k++) { st.kernel_ms[k] += x.kernel_ms[k]; st.kernel_launches[k] += x.kernel_launches[k]; }
+}
+
+// The body of fasim_scan / fasim_scan_queries: every (query, batch of segments) pair is one work item; the worker engines
+// take items from one queue, so the tail of one query's scan overlaps the head of the next (no ramp-up / drain per query).
+// nq == 0: the engine's current query.
+int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rna_lens, int nq, const char* dna, int64_t dna_len,
+	int64_t seg_first, int64_t seg_count, const fasim_params* pp, fasim_result** outs)
+{
+	const bool resident = (dna == nullptr);
+	if (resident) {
+		if (E->dna_host.empty()) return fail(E, FASIM_E_ARG, "no resident DNA: call fasim_load_dna first");
+		dna = E->dna_host.data(); dna_len = (int64_t)E->dna_host.size();
+	}
+	if (!dna || dna_len <= 0 || !pp || !outs) return fail(E, FASIM_E_ARG, "bad arguments");
+	const fasim_params p = *pp;
+	if (p.cutLength <= 0 || p.cutLength - p.overlapLength <= 0) return fail(E, FASIM_E_ARG, "cutLength/overlapLength invalid");
+	if (dna_len > 0x7fffffffll) return fail(E, FASIM_E_ARG, "one record is limited to 2^31-1 nt (the reference's int positions)");
+	HIPOK(hipSetDevice(E->device));
+	const double t_begin = now_s();
+	AffinityScope numa(E->device, E->opt_numa != 0);
+	{ const char* pe = getenv("FASIM_PROFILE"); g_prof.on = pe && atoi(pe) != 0; g_prof.reset(); }
+
+	std::vector<std::string> queries;
+	if (nq <= 0) queries.push_back(E->rna);
+	else for (int q = 0; q < nq; q++) {
+		if (!rnas || !rna_lens || !rnas[q] || rna_lens[q] <= 0) return fail(E, FASIM_E_ARG, "empty query %d", q);
+		queries.emplace_back(rnas[q], rnas[q] + rna_lens[q]);
+	}
+	const int nquery = (int)queries.size();
+	for (int q = 0; q < nquery; q++) outs[q] = nullptr;
+
+	const int64_t nseg_all = fasim_segment_count(dna_len, &p);
+	if (seg_first < 0) seg_first = 0;
+	if (seg_count < 0 || seg_first + seg_count > nseg_all) seg_count = std::max<int64_t>(0, nseg_all - seg_first);
+	const int64_t step = p.cutLength - p.overlapLength;
+	const std::vector<int> encs = enabled_encodings(p);
+	const int nenc = (int)encs.size();
+
+	std::vector<std::vector<HostTriplex>> all(nquery);
+	bool packed = false;
+	std::vector<fasim_scan_stats> qst(nquery);
+	for (auto& x : qst) memset(&x, 0, sizeof x);
+	if (seg_count > 0 && nenc > 0) {
+		// the shard's DNA stays resident for the whole scan (all queries)
+		const int64_t shard_lo = seg_first * step;
+		const int64_t shard_hi = std::min<int64_t>(dna_len, (seg_first + seg_count - 1) * step + p.cutLength);
+		// resident record: the kernels read it in place; host buffer: every batch streams its own slice (scan_batch)
+		const uint8_t* dna_dev = resident ? E->dna_res.as<uint8_t>() + shard_lo : nullptr;
+		(void)shard_hi;
+		const int tstride = (p.cutLength + 15) & ~15;
+		// Batches of ~384 segments x 48 encodings; several batches are in flight at once on worker engines (own HIP
+		// stream + buffers + host thread), so the latency-bound kernels (stripe-faithful re-runs, tracebacks) and the
+		// host-side work of one batch overlap the VALU-bound kernels of another.
+		// (384 rather than 512: a 50 Mb record then gives 27 batches for the 10 workers instead of exactly two rounds of ten, which
+		//  made all workers finish their last batch together: tools/sweep_sched.py, profiles/r02_sched_sweep.txt)
+		int64_t seg_batch = std::max<int64_t>(1, std::min<int64_t>(384, ((int64_t)8 << 30) / ((int64_t)4 * nenc * tstride)));
+		const char* envb = getenv("FASIM_SEG_BATCH");
+		if (envb) seg_batch = std::max(1, atoi(envb));
+		if (E->opt_seg_batch > 0) seg_batch = E->opt_seg_batch;
+		int nworkers = 10;
+		const char* envw = getenv("FASIM_WORKERS");
+		if (envw) nworkers = std::max(1, std::min(16, atoi(envw)));
+		if (E->opt_workers > 0) nworkers = std::min(16, E->opt_workers);
+		// option taper = t (percent): the last t % of the segments go in half-size batches, so that the workers do not all finish
+		// their last batch at the same moment (shorter drain at the end of a scan)
+		int taper_pct = E->opt_taper >= 0 ? E->opt_taper : 0;
+		// Batch size fitted to the record (single-lncRNA scans of >= 128 segments per worker; an explicit seg_batch switches it off): the segments are cut so that every worker gets R whole rounds of batches of at most 512 segments (R = the
+		// fewest rounds that allow it), and the last quarter of the record goes in half-size batches.  The workers then neither
+		// idle through a partial last round nor finish their last full-size batch all at once (the drain of a scan is the
+		// stage 3 of its last batches on an otherwise idle GPU): 50 Mb = 10 204 segments -> 15 batches of 511 + 10 of 255,
+		// 2.41 s against 2.61 s with fixed batches of 384 (profiles/r02_ab_batch_shape.txt: the optimum sits exactly where
+		// the batches tile the ten workers, 448 and 576 are both slower than 512; other record sizes: r02_ab_sizes.txt).
+		// A batch of several lncRNAs is one stream of items, lncRNA after lncRNA, and keeps fixed batches of 384.
+		if (!envb && E->opt_seg_batch <= 0 && nquery == 1 && seg_count >= (int64_t)128 * nworkers) {
+			const int64_t target = 512;
+			const int64_t rounds = std::max<int64_t>(1, (seg_count + target * (int64_t)nworkers - 1) / (target * (int64_t)nworkers));
+			seg_batch = std::max<int64_t>(1, std::min<int64_t>((seg_count + rounds * nworkers - 1) / (rounds * nworkers), ((int64_t)8 << 30) / ((int64_t)4 * nenc * tstride)));
+			if (E->opt_taper < 0) taper_pct = 25;
+		}
+		std::vector<std::pair<int64_t, int64_t>> chunks;
+		{
+			int64_t b0 = seg_first; const int64_t b_end = seg_first + seg_count;
+			const int64_t taper_from = b_end - seg_count * taper_pct / 100;
+			while (b0 < b_end) {
+				int64_t len = (taper_pct > 0 && b0 >= taper_from) ? std::max<int64_t>(1, seg_batch / 2) : seg_batch;
+				len = std::min(len, b_end - b0);
+				chunks.push_back({ b0, b0 + len });
+				b0 += len;
+			}
+		}
+		struct Item { int q; int64_t b0, b1; };
+		std::vector<Item> items;
+		items.reserve(chunks.size() * (size_t)nquery);
+		for (int q = 0; q < nquery; q++) for (const auto& c : chunks) items.push_back({ q, c.first, c.second });
+		nworkers = (int)std::min<size_t>((size_t)nworkers, items.size());
+		// worker 0 is this engine; the others are lazily created engines on the same device
+		while ((int)E->workers.size() < nworkers - 1) {
+			fasim_engine* w = nullptr;
+			int rc = fasim_engine_create(E->device, &w); if (rc) return fail(E, rc, "cannot create worker engine: %s", fasim_last_error(nullptr));
+			E->workers.push_back(w);
+		}
+		std::atomic<int> active_workers(nworkers);
+		std::vector<fasim_engine*> ws(1, E);
+		for (int k = 0; k < nworkers - 1; k++) ws.push_back(E->workers[k]);
+		{
+			const char* envg = getenv("FASIM_HEAVY_GATE");      // heavy kernels in flight at once (0 = no gate)
+			E->own_gate.cap = E->opt_gate >= 0 ? E->opt_gate : (envg ? atoi(envg) : 4);
+		}
+		for (fasim_engine* w : ws) {
+			w->gate = (ws.size() > 1 && E->own_gate.cap > 0) ? &E->own_gate : nullptr;
+			w->scan_v1 = E->scan_v1; w->align_v1 = E->align_v1;
+			w->hz_chunks = E->hz_chunks; w->hz_snap = E->hz_snap; w->hz_target = E->hz_target; w->hz_hot_w = E->hz_hot_w; w->opt_band = E->opt_band;
+			w->host_threads = std::max(1, E->host_threads_total / nworkers);
+			w->host_threads_share_total = E->host_threads_total; w->active_workers = &active_workers;
+			{
+				// -F: the finish half of classic SIM is ~40 ms of host work per unit and nothing else needs the cores meanwhile
+				const int all = E->host_threads_explicit ? E->host_threads_total : usable_cores();
+				w->sim_threads = std::max(1, all / (int)std::max<size_t>(1, std::min<size_t>((size_t)nworkers, items.size())));
+			}
+			HIPOK(hipSetDevice(E->device));
+			int rc = upload(w, w->enc_ids, encs.data(), sizeof(int) * nenc); if (rc) return rc;
+			drain_timed(w);
+			for (int k = 0; k < FASIM_KERNEL_FAMILIES; k++) { w->kernel_ms[k] = 0; w->kernel_launches[k] = 0; }
+		}
+		std::vector<std::vector<HostTriplex>> per_item(items.size());
+		std::vector<fasim_scan_stats> ist(items.size());
+		for (auto& x : ist) memset(&x, 0, sizeof x);
+		std::vector<double> it0(items.size(), 0.0), it1(items.size(), 0.0);
+		std::vector<int> wrc(ws.size(), FASIM_OK);
+		std::atomic<size_t> next(0);
+		// A worker owns an item (one lncRNA x one batch of segments) from its scan phase (stages 1+2) through stage 3.
+		// (A cooperative tail -- the stage 3 of the last batches cut into sub-tasks that idle workers steal -- was built in round 2
+		//  and measured 0.1-0.2 s per 50 Mb scan slower than without it, profiles/r02_ab_trees.txt; it was removed in round 3.)
+		auto run = [&](size_t wi) {
+			CpuScope cpu(28, "CPU seconds: worker threads themselves (HIP calls, lists, decisions)");
+			(void)hipSetDevice(E->device);
+			fasim_engine* w = ws[wi];
+			for (;;) {
+				const size_t c = next.fetch_add(1);
+				if (c >= items.size()) { active_workers.fetch_sub(1); break; }
+				const Item& itx = items[c];
+				const std::string& rq = queries[(size_t)itx.q];
+				it0[c] = now_s();
+				BatchCtx ctx;
+				int r = FASIM_OK;
+				if (w->rna != rq) {          // the worker switches to this item's lncRNA (3 x m bytes H2D)
+					r = fasim_set_query(w, rq.data(), (int)rq.size());
+					if (r && w != E) w->err = std::string("worker set_query failed: ") + w->err;
+				}
+				if (!r) r = scan_batch(w, dna, dna_len, dna_dev, shard_lo, itx.b0, itx.b1, p, encs, tstride, ctx, ist[c]);
+				if (!r && ctx.B.nunit > 0 && !ctx.stage3_done) r = stage3_range(w, ctx, 0, ctx.B.nunit, ist[c]);
+				(void)hipStreamSynchronize(w->st);
+				drain_timed(w);
+				for (int k = 0; k < FASIM_KERNEL_FAMILIES; k++) { ist[c].kernel_ms[k] = w->kernel_ms[k]; ist[c].kernel_launches[k] = w->kernel_launches[k]; w->kernel_ms[k] = 0; w->kernel_launches[k] = 0; }
+				if (!r) collect_batch(ctx, per_item[c]);
+				it1[c] = now_s();
+				if (r) wrc[wi] = r;
+			}
+			(void)hipStreamSynchronize(w->st);
+		};
+		if (g_prof.on) fprintf(stderr, "[fasim prof] scan head (setup before the workers start)  %.3f s\n", now_s() - t_begin);
+		const double t_workers = now_s();
+		if (ws.size() == 1) run(0);
+		else { std::vector<std::thread> th; for (size_t wi = 0; wi < ws.size(); wi++) th.emplace_back(run, wi); for (auto& t : th) t.join(); }
+		for (fasim_engine* w : ws) w->active_workers = nullptr;
+		if (g_prof.on) fprintf(stderr, "[fasim prof] scan workers                                  %.3f s\n", now_s() - t_workers);
+		for (size_t wi = 0; wi < ws.size(); wi++) if (wrc[wi]) { if (ws[wi] != E) E->err = ws[wi]->err; return wrc[wi]; }
+		// a multi-query call leaves the engine on its LAST query (documented in fasim_hip.h)
+		if (nq > 0 && E->rna != queries.back()) { int rc = fasim_set_query(E, queries.back().data(), (int)queries.back().size()); if (rc) return rc; }
+		const double t_merge = now_s();
+		std::vector<double> q0(nquery, 1e300), q1(nquery, 0.0);
+		std::vector<std::vector<const std::vector<HostTriplex>*>> parts((size_t)nquery);
+		for (size_t c = 0; c < items.size(); c++) {
+			const int q = items[c].q;
+			parts[(size_t)q].push_back(&per_item[c]);
+			add_stats(qst[(size_t)q], ist[c]);
+			q0[q] = std::min(q0[q], it0[c]); q1[q] = std::max(q1[q], it1[c]);
+		}
+		// per query: wall clock from the start of its first batch to the end of its last one (neighbouring queries overlap)
+		for (int q = 0; q < nquery; q++) qst[(size_t)q].t_total_s = nquery == 1 ? 0.0 : std::max(0.0, q1[q] - q0[q]);
+		if (nquery == 1) qst[0].t_total_s = now_s() - t_begin;
+		// the records go straight from the batches' lists into the C result (the batches side by side on the host threads);
+		// the lists themselves (half a million strings for a 50 Mb record) are freed behind the caller's back
+		for (int q = 0; q < nquery; q++) {
+			const int rc = pack_result_parts(E, parts[(size_t)q], qst[(size_t)q], E->host_threads_total, &outs[q]);
+			if (rc) { for (int k = 0; k < q; k++) { fasim_result_free(outs[k]); outs[k] = nullptr; } return rc; }
+		}
+		if (nquery == 1) outs[0]->stats.t_total_s = now_s() - t_begin;
+		if (g_prof.on) fprintf(stderr, "[fasim prof] scan tail: packing the records                        %.3f s\n", now_s() - t_merge);
+		// Free the batches' lists (half a million strings for a 50 Mb record) here, side by side on the host threads, while the
+		// GPU is idle: left to a background thread the unmapping runs into the first kernels of the caller's next scan and
+		// stretches them by half (the driver's MMU notifier stalls the queues while the address space changes: tools/iso_probe.py,
+		// profiles/r02_ab_reaper.txt).
+		{
+			std::atomic<size_t> nextf(0);
+			auto freer = [&]() { for (;;) { const size_t c = nextf.fetch_add(1); if (c >= per_item.size()) break; std::vector<HostTriplex>().swap(per_item[c]); } };
+			const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, E->host_threads_total), per_item.size()));
+			if (nt == 1) freer();
+			else { std::vector<std::thread> th; for (int k = 0; k < nt; k++) th.emplace_back(freer); for (auto& t : th) t.join(); }
+		}
+		if (g_prof.on) fprintf(stderr, "[fasim prof] scan tail: packing + freeing the batches' lists        %.3f s\n", now_s() - t_merge);
+		packed = true;
+	}
+
+	if (!packed) {
+		// (nothing to scan: empty results)
+		if (nquery == 1) qst[0].t_total_s = now_s() - t_begin;
+		for (int q = 0; q < nquery; q++) {
+			const int rc = pack_result(E, all[(size_t)q], qst[(size_t)q], &outs[q]);
+			if (rc) { for (int k = 0; k < q; k++) { fasim_result_free(outs[k]); outs[k] = nullptr; } return rc; }
+		}
+		if (nquery == 1) outs[0]->stats.t_total_s = now_s() - t_begin;
+	}
+	if (g_prof.on) {
+		static long seen = 0; const long now_r = g_dev_reallocs.load();
+		fprintf(stderr, "[fasim prof] device buffer (re)allocations during this scan: %ld\n", now_r - seen); seen = now_r;
+		double tot = now_s() - t_begin;
+		fprintf(stderr, "[fasim prof] total %.3f s  stage2 %.3f  stage3 %.3f  host %.3f\n", tot, qst[0].t_stage2_s, qst[0].t_stage3_s, qst[0].t_host_s);
+		g_prof.dump();
+	}
+	return FASIM_OK;
+}
+
