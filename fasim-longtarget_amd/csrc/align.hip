@@ -684,10 +684,8 @@ __global__ void __launch_bounds__(64) k_finish(const uint8_t* __restrict__ tcode
 //   words  0..31 : banded: h_b (lo16) / e_b (hi16)
 //   words 32..63 : banded: h_c (lo16)
 // ------------------------------------------------------------------------------------------------
-constexpr int FL_WORDS = 64;
-constexpr int FL_RING = 64;
-constexpr int FL_W = 32;              // max band array width (2*band+3)
-constexpr int FL_CELLS = 2048;        // direction cells per alignment
+// Two sizes: WORDS = 64 (16 KB per workgroup; ring of 64 rows, band arrays of 32, 2 048 direction cells: 97.7 % of the alignments of
+// the bench) and WORDS = 256 (64 KB; ring 256, band arrays 128, 16 384 cells) for what comes back from the small one with status 2.
 
 struct LdsArena {
 	uint32_t* base;                   // &lds[threadIdx.x]; word k lives at base[k * 64]
@@ -700,6 +698,7 @@ struct LdsArena {
 
 constexpr int GL_NEG = -30000;        // int16-safe "minus infinity" of the reverse pass
 
+template <int FL_RING>
 __device__ int reverse_pass_lds(const uint8_t* __restrict__ tw, const uint8_t* __restrict__ q, int S, int ref_end, int read_end,
 	const LdsArena& A, int* ref_begin, int* read_begin)
 {
@@ -741,11 +740,13 @@ __device__ int reverse_pass_lds(const uint8_t* __restrict__ tw, const uint8_t* _
 	return 1;
 }
 
+template <int FL_WORDS, int FL_CELLS>
 __global__ void __launch_bounds__(64) k_finish_lds(const uint8_t* __restrict__ tcodes, const uint8_t* __restrict__ qcodes,
 	const FwdProb* __restrict__ probs, const FwdOut* __restrict__ fwd, const int32_t* __restrict__ order, int32_t nprob,
 	uint8_t* __restrict__ dirs, AlignOutDev* __restrict__ out, uint32_t* __restrict__ cigar_pool, uint32_t pool_cap,
 	uint32_t* __restrict__ pool_count)
 {
+	constexpr int FL_RING = FL_WORDS, FL_W = FL_WORDS / 2;      // ring of the reverse pass; max band array width (2*band+3), h_c behind h_b/e_b
 	__shared__ uint32_t lds[FL_WORDS * 64];
 	const int gid = blockIdx.x * blockDim.x + threadIdx.x;
 	if (gid >= nprob) return;
@@ -765,7 +766,7 @@ __global__ void __launch_bounds__(64) k_finish_lds(const uint8_t* __restrict__ t
 		// 148..250: an F >= 132 is possible in the reverse pass of the 8-bit kernel; >= 251 runs on the reference's
 		// 16-bit kernels, whose compare is not affected
 		if (fo.score >= 148 && fo.score < 255 - BIAS) { o->status = 11; return; }
-		const int r = reverse_pass_lds(tw, qcodes, fo.score, fo.ref_end, fo.read_end, A, &ref_begin, &read_begin);
+		const int r = reverse_pass_lds<FL_RING>(tw, qcodes, fo.score, fo.ref_end, fo.read_end, A, &ref_begin, &read_begin);
 		if (r) { o->status = r == 2 ? 2 : 11; return; }
 	}
 	o->ref_begin = ref_begin; o->query_begin = read_begin;
@@ -784,7 +785,7 @@ __global__ void __launch_bounds__(64) k_finish_lds(const uint8_t* __restrict__ t
 			if (i + band < end) end = i + band;
 			const int edge = end + 1 < width - 1 ? end + 1 : width - 1;
 			int f = 0;
-			A.set(0, 0, 0); A.set(edge, 0, 0); A.set_lo(32, 0);               // h_b[0]=e_b[0]=h_b[edge]=e_b[edge]=h_c[0]=0
+			A.set(0, 0, 0); A.set(edge, 0, 0); A.set_lo(FL_W, 0);               // h_b[0]=e_b[0]=h_b[edge]=e_b[edge]=h_c[0]=0
 			const int x = i - band > 0 ? i - band : 0;
 			const int xp = i - 1 - band > 0 ? i - 1 - band : 0;
 			const int rd = read[i];
@@ -796,7 +797,7 @@ __global__ void __launch_bounds__(64) k_finish_lds(const uint8_t* __restrict__ t
 				int t2 = i == 0 ? -GAP_EXT : A.hi(e) - GAP_EXT;
 				const int ev = t1 > t2 ? t1 : t2;
 				const int de = t1 > t2 ? 1 : 0;
-				t1 = A.lo(32 + b) - GAP_OPEN;
+				t1 = A.lo(FL_W + b) - GAP_OPEN;
 				t2 = f - GAP_EXT;
 				f = t1 > t2 ? t1 : t2;
 				const int df = t1 > t2 ? 1 : 0;
@@ -806,13 +807,13 @@ __global__ void __launch_bounds__(64) k_finish_lds(const uint8_t* __restrict__ t
 				t2 = A.lo(d) + swsc(ref[j], rd);                                  // h_b[d] (still the previous row's)
 				const int hv = t1 > t2 ? t1 : t2;
 				A.set_hi(u, ev);                                                  // e_b[u]
-				A.set_lo(32 + u, hv);                                             // h_c[u]
+				A.set_lo(FL_W + u, hv);                                             // h_c[u]
 				if (hv > maxv) maxv = hv;
 				const int dh = (t1 <= t2) ? 0 : (e1 > f1 ? 1 : 2);
 				// bit0: E opened (3) vs extended (2); bit1: F opened (5) vs extended (4); bits 2-3: H from diag / E / F
 				dir[(int64_t)(rowcell + (j - x)) * 64] = (uint8_t)(de | (df << 1) | (dh << 2));
 			}
-			for (int j = 1; j <= u; j++) A.set_lo(j, A.lo(32 + j));               // h_b[j] = h_c[j]
+			for (int j = 1; j <= u; j++) A.set_lo(j, A.lo(FL_W + j));               // h_b[j] = h_c[j]
 		}
 		band *= 2;
 		if (maxv < score && band > 4 * (refLen + readLen) + 16) { o->status = 3; return; }
@@ -867,7 +868,20 @@ hipError_t launch_finish(const uint8_t* tcodes, const uint8_t* qcodes, const Fwd
 	if (nprob <= 0) return hipSuccess;
 	hipError_t err = hipMemsetAsync(pool_count, 0, sizeof(uint32_t), st);
 	if (err != hipSuccess) return err;
-	hipLaunchKernelGGL(k_finish_lds, dim3((nprob + 63) / 64), dim3(64), 0, st, tcodes, qcodes, probs, fwd, order, nprob, dirs, out,
+	hipLaunchKernelGGL((k_finish_lds<64, 2048>), dim3((nprob + 63) / 64), dim3(64), 0, st, tcodes, qcodes, probs, fwd, order, nprob, dirs, out,
+		cigar_pool, pool_cap, pool_count);
+	return hipGetLastError();
+}
+
+// the same kernel with four times the LDS per alignment for the listed ones (results to out[idx_list[k]], cigars appended to the
+// same pool); `dirs` must hold ceil(nlist/64) * 64 * 16384 bytes
+hipError_t launch_finish_mid(const uint8_t* tcodes, const uint8_t* qcodes, const FwdProb* probs, const FwdOut* fwd, const int32_t* idx_list,
+	int32_t nlist, uint8_t* dirs, AlignOutDev* out, uint32_t* cigar_pool, uint32_t pool_cap, uint32_t* pool_count, hipStream_t st)
+{
+	if (nlist <= 0) return hipSuccess;
+	static bool attr_set = false;                   // (benign race: the call is idempotent)
+	if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_finish_lds<256, 16384>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr_set = true; }
+	hipLaunchKernelGGL((k_finish_lds<256, 16384>), dim3((nlist + 63) / 64), dim3(64), 0, st, tcodes, qcodes, probs, fwd, idx_list, nlist, dirs, out,
 		cigar_pool, pool_cap, pool_count);
 	return hipGetLastError();
 }

@@ -459,8 +459,26 @@ int run_finish(fasim_engine* E, const UnitBatch& B, const std::vector<WindowProb
 	HIPOK(hipMemcpyAsync(&pool_used, E->cigcount.p, sizeof pool_used, hipMemcpyDeviceToHost, E->st));
 	HIPOK(hipStreamSynchronize(E->st));
 	{
-		// alignments whose band / direction matrix did not fit the LDS kernel: same algorithm on global scratch, first
-		// with 16 KB per alignment, then (wide bands after several doublings: gapped alignments) with 1 MB
+		// alignments whose band / direction matrix did not fit the LDS kernel (2.3 % on the bench): the same kernel with four times
+		// the LDS per alignment (64 KB per workgroup) first; only what does not fit that either goes to global scratch below
+		std::vector<int32_t> mid;
+		for (int k = 0; k < n; k++) if (ao[k].status == 2) mid.push_back(k);
+		if (!mid.empty()) {
+			if (g_prof.on) g_prof.add(30, "finish: alignments sent to the 64 KB LDS pass (count)", 1e-6 * mid.size());
+			rc = upload(E, E->unit_ids, mid.data(), sizeof(int32_t) * mid.size()); if (rc) return rc;
+			HIPOK(E->scratch2.ensure((size_t)((mid.size() + 63) / 64) * 64 * 16384));
+			{ TimedScope ts(E, 3);
+			he = launch_finish_mid(tcv(E), E->q2.as<uint8_t>(), E->fprobs.as<FwdProb>(), E->fout.as<FwdOut>(), E->unit_ids.as<int32_t>(), (int)mid.size(),
+				E->scratch2.as<uint8_t>(), E->aout.as<AlignOutDev>(), E->cigpool.as<uint32_t>(), (uint32_t)pool_cap, E->cigcount.as<uint32_t>(), E->st); }
+			if (he != hipSuccess) return fail(E, FASIM_E_HIP, "finish (64 KB LDS) launch failed: %s", hipGetErrorString(he));
+			HIPOK(hipMemcpyAsync(ao.data(), E->aout.p, sizeof(AlignOutDev) * n, hipMemcpyDeviceToHost, E->st));
+			HIPOK(hipMemcpyAsync(&pool_used, E->cigcount.p, sizeof pool_used, hipMemcpyDeviceToHost, E->st));
+			HIPOK(hipStreamSynchronize(E->st));
+		}
+	}
+	{
+		// then the same algorithm on global scratch, first with 16 KB per alignment, then (wide bands after several doublings:
+		// gapped alignments) with 1 MB
 		const int caps[2] = { scratch_cap, 1 << 20 };
 		for (int pass = 0; pass < 2; pass++) {
 			std::vector<int32_t> big;

@@ -105,6 +105,8 @@ hipError_t launch_align_fwd(const FwdLaunch& L, hipStream_t st);     // hipError
 hipError_t launch_finish(const uint8_t* tcodes, const uint8_t* qcodes, const FwdProb* probs, const FwdOut* fwd, const int32_t* order,
 	int32_t nprob, uint8_t* dirs, AlignOutDev* out, uint32_t* cigar_pool, uint32_t pool_cap, uint32_t* pool_count, hipStream_t st);
 
+hipError_t launch_finish_mid(const uint8_t* tcodes, const uint8_t* qcodes, const FwdProb* probs, const FwdOut* fwd, const int32_t* idx_list,
+	int32_t nlist, uint8_t* dirs, AlignOutDev* out, uint32_t* cigar_pool, uint32_t pool_cap, uint32_t* pool_count, hipStream_t st);
 hipError_t launch_finish_big(const uint8_t* tcodes, const uint8_t* qcodes, const FwdProb* probs, const FwdOut* fwd,
 	const int32_t* idx_list, int32_t nlist, uint8_t* scratch, int32_t scratch_cap, AlignOutDev* out, uint32_t* cigar_pool,
 	uint32_t pool_cap, uint32_t* pool_count, hipStream_t st);
