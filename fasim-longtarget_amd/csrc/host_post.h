@@ -52,6 +52,26 @@ float triplex_stability(char c1, char c2, int para);                    // tripl
 // left (consumed).  Appends the unit's triplexes (nt within [ntMin, ntMax]) in the reference's order.  host_sim.cpp
 void sim_finish_unit(const std::string& rna, const std::string& target, const std::string& src, long dna_start, long min_score,
 	int enc, const fasim_params& p, std::vector<fasim_sim_node>& nodes, std::vector<HostTriplex>& out);
+// The same as a state machine, one round at a time, so that the re-sweeps of all units of a slice can run on the device between
+// the rounds (k_sim_resweep, sim.hip): next_round() = sim.h:572-883 (best node, linear-space traceback, triplex record); it returns
+// false when the unit is finished.  *sweep: a re-sweep of the node's rectangle box = {m1, mm, n1, nn} follows (not after the last
+// node); new_pairs (optional) receives the (query row, target column) pairs the traceback has just marked as used.  The caller
+// then updates `nodes` / `floor_score` by the device kernel or by resweep_host().
+struct SimUnit {
+	std::vector<fasim_sim_node> nodes;
+	std::vector<HostTriplex> out;
+	long floor_score = 0;            // the reference's `min`: 0, then 1 (addnode's return value)
+	long rounds_left = 0;
+	SimUnit(const std::string& rna, const std::string& target, const std::string& src, long dna_start, long min_score, int enc,
+		const fasim_params& p, std::vector<fasim_sim_node>&& nodes);
+	~SimUnit();
+	SimUnit(const SimUnit&) = delete;
+	SimUnit& operator=(const SimUnit&) = delete;
+	bool next_round(bool* sweep, int box[4], std::vector<std::pair<int, int>>* new_pairs);
+	void resweep_host();
+private:
+	struct Impl; Impl* im;
+};
 // tail of fastSIM (fastsim.h:273-288): sort/unique/sort/unique/sort, top 50, identity/stability/nt filter
 void dedup_top(std::vector<HostTriplex>& mine, const fasim_params& p, std::vector<HostTriplex>& out);
 

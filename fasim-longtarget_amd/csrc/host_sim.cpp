@@ -162,85 +162,127 @@ struct Work {
 
 } // namespace
 
-void sim_finish_unit(const std::string& rna, const std::string& target, const std::string& src, long dna_start, long min_score,
-	int enc, const fasim_params& p, std::vector<fasim_sim_node>& nodes, std::vector<HostTriplex>& out)
-{
-	const EncInfo info = enc_info(enc);
-	const std::string a1 = ' ' + rna, b1 = ' ' + target;
+// ---- one unit of the -F path as a state machine: next_round() = sim.h:572-883 (best node, traceback, record), then the re-sweep of
+//      the influenced rectangle either on the device (k_sim_resweep, sim.hip) or here (resweep_host) --------------------------------
+struct SimUnit::Impl {
+	std::string a1, b1, src;
 	Work w;
-	w.A = a1.c_str(); w.B = b1.c_str(); w.M = (long)rna.size(); w.N = (long)target.size();
+	EncInfo info;
+	fasim_params p;
+	long dna_start = 0, min_score = 0;
+	long m1 = 0, mm = 0, n1 = 0, nn = 0;              // bounding box of the node of the current round
+};
+
+SimUnit::SimUnit(const std::string& rna, const std::string& target, const std::string& src_, long dna_start, long min_score, int enc,
+	const fasim_params& p, std::vector<fasim_sim_node>&& nodes_) : nodes(std::move(nodes_)), im(new Impl())
+{
+	Impl& I = *im;
+	I.a1 = ' ' + rna; I.b1 = ' ' + target; I.src = src_;
+	I.info = enc_info(enc); I.p = p; I.dna_start = dna_start; I.min_score = min_score;
+	Work& w = I.w;
+	w.A = I.a1.c_str(); w.B = I.b1.c_str(); w.M = (long)rna.size(); w.N = (long)target.size();
 	w.list = &nodes;
-	const long M = w.M, N = w.N;
-	w.CC.assign((size_t)N + 1, 0); w.DD = w.RR = w.SS = w.EE = w.FF = w.CC;
-	w.HH.assign((size_t)M + 1, 0); w.WW = w.II = w.JJ = w.XX = w.YY = w.HH;
-	w.used.assign((size_t)M + 2, std::vector<int>());
-	w.script.assign((size_t)(M + N + 2), 0);
+	w.CC.assign((size_t)w.N + 1, 0); w.DD = w.RR = w.SS = w.EE = w.FF = w.CC;
+	w.HH.assign((size_t)w.M + 1, 0); w.WW = w.II = w.JJ = w.XX = w.YY = w.HH;
+	w.used.assign((size_t)w.M + 2, std::vector<int>());
+	w.script.assign((size_t)(w.M + w.N + 2), 0);
+	rounds_left = (long)nodes.size();
+}
+SimUnit::~SimUnit() { delete im; }
+
+bool SimUnit::next_round(bool* sweep, int box[4], std::vector<std::pair<int, int>>* new_pairs)
+{
+	*sweep = false;
+	if (rounds_left <= 0 || nodes.empty()) return false;
+	Impl& I = *im; Work& w = I.w;
+	w.list = &nodes;
+	const fasim_params& p = I.p; const EncInfo& info = I.info;
+	const long N = w.N;
+	const long round = --rounds_left;
+	size_t best = 0;
+	for (size_t k = 1; k < nodes.size(); k++) if (nodes[k].score > nodes[best].score) best = k;
+	const fasim_sim_node cur = nodes[best];
+	if (best != nodes.size() - 1) nodes[best] = nodes.back();
+	nodes.pop_back();
+	long score = cur.score;
+	const long stari = cur.stari + 1, starj = cur.starj + 1, endi = cur.endi, endj = cur.endj;
+	I.m1 = cur.top; I.mm = cur.bot; I.n1 = cur.left; I.nn = cur.right;
+	const long rl = endi - stari + 1, cl = endj - starj + 1;
+	w.I = stari - 1; w.J = starj - 1; w.sp = w.script.data(); w.last = 0;
+	const int nt = (int)(endi - stari + 1);
+	// the pairs this alignment uses (DIAG) are what the re-sweep must exclude: remember where the rows' lists stood
+	std::vector<size_t> before;
+	if (new_pairs) { before.resize((size_t)rl + 2); for (long i = 0; i <= rl + 1 && stari - 1 + i <= w.M + 1; i++) before[(size_t)i] = w.used[(size_t)(stari - 1 + i)].size(); }
+	w.diff(w.A + stari - 1, w.B + starj - 1, rl, cl, kQ, kQ);
+	if (new_pairs) {
+		new_pairs->clear();
+		for (long i = 0; i <= rl + 1 && stari - 1 + i <= w.M + 1; i++) {
+			const std::vector<int>& u = w.used[(size_t)(stari - 1 + i)];
+			for (size_t k = before[(size_t)i]; k < u.size(); k++) new_pairs->push_back({ (int)(stari - 1 + i), u[k] });
+		}
+	}
+	if ((double)score / 10.0 <= (double)I.min_score) { rounds_left = 0; return false; }             // sim.h:594
+
+	// aligned strings and identity (display, sim.h:348-389)
+	std::string tfo, tgt;
+	long matches = 0, others = 0;
+	{
+		const char* a = w.A + stari - 1; const char* b = w.B + starj - 1; const long* S = w.script.data();
+		long i = 0, j = 0;
+		while (i < rl || j < cl) {
+			while (i < rl && j < cl && *S == 0) { ++i; ++j; if (a[i] == b[j]) ++matches; else ++others; tfo += a[i]; tgt += b[j]; S++; }
+			if (i < rl || j < cl) {
+				const long op = *S++;
+				if (op > 0) for (long f = 0; f < op; f++) { tfo += '-'; tgt += b[++j]; ++others; }
+				else for (long f = 0; f < -op; f++) { tgt += '-'; tfo += a[++i]; ++others; }
+			}
+		}
+	}
+	const float identity = (float)(100 * matches) / (float)(matches + others);
+	if (nt >= p.ntMin && nt <= p.ntMax) {
+		// mean stability with the TT / CC run penalties (sim.h:696-731); the TTS string is read from the display strand
+		float tri = 0.0f, before_h = 0.0f;
+		char prev = 0, curc = 0;
+		std::string tts;
+		long j = 0;
+		for (size_t k = 0; k < tgt.size(); k++) {
+			float h;
+			if (tgt[k] == '-') { curc = '-'; h = triplex_stability(curc, tfo[k], info.para); tts += '-'; }
+			else { curc = I.src[(size_t)(starj + j - 1)]; h = triplex_stability(curc, tfo[k], info.para); tts += curc; j++; }
+			if (curc == prev && curc == 'T') { tri = tri - before_h + (float)p.penaltyT; h = (float)p.penaltyT; }
+			if (curc == prev && curc == 'C') { tri = tri - before_h + (float)p.penaltyC; h = (float)p.penaltyC; }
+			before_h = h;
+			if (tgt[k] != '-') prev = curc;
+			tri += h;
+		}
+		score /= 10;
+		tri /= nt;
+		long ref_start, ref_end;
+		if (info.para < 0 && info.strand == 0) { ref_start = N - endj + 1; ref_end = N - starj + 1; }
+		else if (info.para > 0 && info.strand == 1) { ref_start = N - endj - 1; ref_end = N - starj - 1; }
+		else { ref_start = starj; ref_end = endj; }
+		HostTriplex t;
+		t.stari = (int)stari; t.endi = (int)endi; t.starj = (int)(ref_start + I.dna_start); t.endj = (int)(ref_end + I.dna_start);
+		t.strand = info.strand; t.reverse = info.para; t.rule = info.rule; t.nt = nt;
+		t.score = (float)score; t.identity = identity; t.tri_score = tri;
+		t.tfo = tfo; t.tts = tts;
+		out.push_back(std::move(t));
+	}
+	if (round == 0) return false;                        // the last node: no re-sweep (sim.h:884)
+	*sweep = true;
+	box[0] = (int)I.m1; box[1] = (int)I.mm; box[2] = (int)I.n1; box[3] = (int)I.nn;
+	return true;
+}
+
+// ---- re-sweep of the influenced rectangle on the host (sim.h:884-1141): fasim_sim_finish_unit and the device path's self-check
+void SimUnit::resweep_host()
+{
+	Impl& I = *im; Work& w = I.w;
+	w.list = &nodes;
 	auto& CC = w.CC; auto& DD = w.DD; auto& RR = w.RR; auto& SS = w.SS; auto& EE = w.EE; auto& FF = w.FF;
 	auto& HH = w.HH; auto& WW = w.WW; auto& II = w.II; auto& JJ = w.JJ; auto& XX = w.XX; auto& YY = w.YY;
-	long floor_score = 0;                                 // the reference's `min`: 0, then 1 (addnode's return value)
-	for (long round = (long)nodes.size() - 1; round >= 0; round--) {
-		size_t best = 0;
-		for (size_t k = 1; k < nodes.size(); k++) if (nodes[k].score > nodes[best].score) best = k;
-		const fasim_sim_node cur = nodes[best];
-		if (best != nodes.size() - 1) nodes[best] = nodes.back();
-		nodes.pop_back();
-		long score = cur.score;
-		const long stari = cur.stari + 1, starj = cur.starj + 1, endi = cur.endi, endj = cur.endj;
-		long m1 = cur.top, mm = cur.bot, n1 = cur.left, nn = cur.right;
-		long rl = endi - stari + 1, cl = endj - starj + 1;
-		w.I = stari - 1; w.J = starj - 1; w.sp = w.script.data(); w.last = 0;
-		const int nt = (int)(endi - stari + 1);
-		w.diff(w.A + stari - 1, w.B + starj - 1, rl, cl, kQ, kQ);
-		if ((double)score / 10.0 <= (double)min_score) break;             // sim.h:594
-
-		// aligned strings and identity (display, sim.h:348-389)
-		std::string tfo, tgt;
-		long matches = 0, others = 0;
-		{
-			const char* a = w.A + stari - 1; const char* b = w.B + starj - 1; const long* S = w.script.data();
-			long i = 0, j = 0;
-			while (i < rl || j < cl) {
-				while (i < rl && j < cl && *S == 0) { ++i; ++j; if (a[i] == b[j]) ++matches; else ++others; tfo += a[i]; tgt += b[j]; S++; }
-				if (i < rl || j < cl) {
-					const long op = *S++;
-					if (op > 0) for (long f = 0; f < op; f++) { tfo += '-'; tgt += b[++j]; ++others; }
-					else for (long f = 0; f < -op; f++) { tgt += '-'; tfo += a[++i]; ++others; }
-				}
-			}
-		}
-		const float identity = (float)(100 * matches) / (float)(matches + others);
-		if (nt >= p.ntMin && nt <= p.ntMax) {
-			// mean stability with the TT / CC run penalties (sim.h:696-731); the TTS string is read from the display strand
-			float tri = 0.0f, before = 0.0f;
-			char prev = 0, curc = 0;
-			std::string tts;
-			long j = 0;
-			for (size_t k = 0; k < tgt.size(); k++) {
-				float h;
-				if (tgt[k] == '-') { curc = '-'; h = triplex_stability(curc, tfo[k], info.para); tts += '-'; }
-				else { curc = src[(size_t)(starj + j - 1)]; h = triplex_stability(curc, tfo[k], info.para); tts += curc; j++; }
-				if (curc == prev && curc == 'T') { tri = tri - before + (float)p.penaltyT; h = (float)p.penaltyT; }
-				if (curc == prev && curc == 'C') { tri = tri - before + (float)p.penaltyC; h = (float)p.penaltyC; }
-				before = h;
-				if (tgt[k] != '-') prev = curc;
-				tri += h;
-			}
-			score /= 10;
-			tri /= nt;
-			long ref_start, ref_end;
-			if (info.para < 0 && info.strand == 0) { ref_start = N - endj + 1; ref_end = N - starj + 1; }
-			else if (info.para > 0 && info.strand == 1) { ref_start = N - endj - 1; ref_end = N - starj - 1; }
-			else { ref_start = starj; ref_end = endj; }
-			HostTriplex t;
-			t.stari = (int)stari; t.endi = (int)endi; t.starj = (int)(ref_start + dna_start); t.endj = (int)(ref_end + dna_start);
-			t.strand = info.strand; t.reverse = info.para; t.rule = info.rule; t.nt = nt;
-			t.score = (float)score; t.identity = identity; t.tri_score = tri;
-			t.tfo = tfo; t.tts = tts;
-			out.push_back(std::move(t));
-		}
-		if (round == 0) continue;
-
-		// ---- re-sweep of the influenced rectangle (sim.h:884-1141) ------------------------------------------------------
+	long m1 = I.m1, mm = I.mm, n1 = I.n1, nn = I.nn, rl = 0, cl = 0;
+	{
 		bool positive = false;
 		for (long j = nn; j >= n1; j--) { CC[(size_t)j] = 0; EE[(size_t)j] = j; DD[(size_t)j] = -kQ; FF[(size_t)j] = j; RR[(size_t)j] = SS[(size_t)j] = mm + 1; }
 		auto outside = [&](const P3& x) { return x.i > rl && x.j > cl; };
@@ -311,6 +353,16 @@ void sim_finish_unit(const std::string& rna, const std::string& target, const st
 			}
 		}
 	}
+}
+
+void sim_finish_unit(const std::string& rna, const std::string& target, const std::string& src, long dna_start, long min_score,
+	int enc, const fasim_params& p, std::vector<fasim_sim_node>& nodes, std::vector<HostTriplex>& out)
+{
+	SimUnit u(rna, target, src, dna_start, min_score, enc, p, std::move(nodes));
+	bool sweep = false; int box[4];
+	while (u.next_round(&sweep, box, nullptr)) if (sweep) u.resweep_host();
+	for (HostTriplex& t : u.out) out.push_back(std::move(t));
+	nodes = std::move(u.nodes);
 }
 
 } // namespace fasim
