@@ -89,6 +89,27 @@ struct SimFwdArgs {
 	int32_t* node_count;        // [unit]
 };
 
+// ---- row f3: the re-sweeps of classic SIM between the K rounds (sim.hip, k_sim_resweep) --------------------------------------
+struct SimRoundReq { int32_t active, m1, mm, n1, nn, floor_score, pairs_first, pairs_count; };   // active: 1 = new round (bounding box of its node, its traceback's used pairs), 2 = carry on
+struct SimSweepState { int32_t phase, i, m1, n1, rl, cl, floor_score, nround, grow_rows, grow_cols, positive, pad; };   // an unfinished re-sweep between two launches
+struct SimResweepArgs {
+	const uint8_t* tcodes; const int32_t* unit_len; int32_t tstride;
+	const uint8_t* qcodes; int32_t m;
+	const SimRoundReq* req;         // [unit]
+	const uint32_t* pairs;          // (query row << 16) | target column, 1-based, of all units' requests
+	uint16_t* usedc;                // [unit][SIM_K][col_stride]: the same per target column (the query row aligned to it)
+	uint16_t* used; int32_t* used_cnt;   // [unit][SIM_K][m + 2]: per round the target column aligned to the query row (0 = none); [unit]: rounds swept so far
+	uint64_t* colS; uint64_t* colG; // [unit][col_stride]: per target column the DP state across the sweep line (CC/RR/EE and DD/SS/FF of sim.h as one key each)
+	uint64_t* rowS; uint64_t* rowG; // [unit][row_stride]: per query row (HH/II/JJ and WW/XX/YY)
+	int64_t col_stride, row_stride;
+	SimNodeDev* nodes; int32_t* node_count;      // [unit][SIM_K] in / out, list order = lane order
+	int32_t* floor_out;             // [unit]: the reference's `min` after the round (0, then 1)
+	int32_t* pending;               // [unit]: 1 = out of budget, to be continued
+	SimSweepState* state;           // [unit]
+	int32_t budget;                 // 64-cell steps per unit and launch
+	uint64_t* debug;                // FASIM_SIM_DEBUG=1: 3 x (count, 100 MHz ticks) summed over the units: backward steps, forward steps, events
+};
+
 // packed 4-bit score table: entry q (0..5) of row t = score(t,q)+BIAS
 struct ScoreLut { uint32_t row[5]; };
 

@@ -87,7 +87,8 @@ struct fasim_engine {
 		stage1, hits, hits_total, hit_off, hit_cnt, thr, ends, bprobs, bout, scratch, colmax16, unit_ids, flags, stage1_in, hits2,
 		fprobs, ftasks, fstream, fout, aout, cigpool, cigcount, forder, scratch2, boundary, fboundary, unit_hz,
 		unit_first, hz_cols, hz_plan, hz_base, hz_items, snap, hz_state, hz_rows, hz_chunk, hz_src, hz_zero,   // chunked hazard re-run
-		qsim, sim_min, sim_row, sim_ev, sim_cnt, sim_nodes;      // -F: query codes of the SIM alphabet, thresholds, strip row buffer, events, counters
+		qsim, sim_min, sim_row, sim_ev, sim_cnt, sim_nodes,      // -F: query codes of the SIM alphabet, thresholds, strip row buffer, events, counters
+		sim_req, sim_pairs, sim_used, sim_rounds, sim_col, sim_rowst, sim_floor, sim_pending, sim_state, sim_usedc, sim_debug;   // -F re-sweeps: per-round requests, used pairs, DP state per column / row
 	bool align_v1 = false;        // FASIM_ALIGN_V1=1: force the stripe-faithful kernels for stage 3
 	std::vector<fasim_engine*> workers;   // extra engines on the same device: batches in flight concurrently
 	// Gate for the two GPU-filling kernels (k_scan, k_align_fwd).  Without it the workers fall into lock step: all of them
@@ -375,6 +376,8 @@ int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t*
 	const fasim_params& p, const std::vector<int>& encs, int tstride, BatchCtx& C, fasim_scan_stats& st);
 int sim_forward_units(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, const int32_t* unit_len_dev, const int32_t* unit_len_host,
 	int first, int nunit, const int64_t* mins, std::atomic<int>* ready, std::vector<std::vector<fasim_sim_node>>& lists);
+int sim_resweep_rounds(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, const int32_t* unit_len_dev, const int32_t* unit_len_host,
+	int first, int cnt, SimUnit* const* units, int nthreads);
 int pack_result(fasim_engine* E, std::vector<HostTriplex>& all, const fasim_scan_stats& st, fasim_result** out);
 int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rna_lens, int nq, const char* dna, int64_t dna_len,
 	int64_t seg_first, int64_t seg_count, const fasim_params* pp, fasim_result** outs);

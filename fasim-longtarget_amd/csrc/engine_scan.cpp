@@ -1,6 +1,7 @@
 // fasim-longtarget_amd/csrc/engine_scan.cpp -- batches and workers: scan_batch (segments -> units -> stages 1+2 of one batch), the
 // forward sweep of -F, result packing, and scan_core (work queue of (lncRNA, batch) items over the worker engines).
 #include "engine.h"
+#include <memory>
 
 // ---- row f3: forward sweep of classic SIM ---------------------------------------------------------------------
 // addnode() (sim.h:99-148) over the events of one unit in row-major order: a known start point is updated (strictly larger
@@ -18,12 +19,25 @@ int sim_forward_units(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, c
 	if (nrun <= 0) return FASIM_OK;
 	int maxlen = 1;
 	for (int u = 0; u < nrun; u++) maxlen = std::max(maxlen, unit_len_host[first + u]);
-	if (E->m > 65535 || maxlen > 65535) return fail(E, FASIM_E_UNSUPPORTED, "the SIM forward sweep holds start points in 16 bits: query %d / target %d nt is too long", E->m, maxlen);
+	if (E->m > 65534 || maxlen > 65534) return fail(E, FASIM_E_UNSUPPORTED, "the SIM forward sweep holds start points in 16 bits: query %d / target %d nt is too long", E->m, maxlen);
 	const int64_t row_stride = (maxlen + 2 + 15) & ~15;
 	const uint32_t cap = (uint32_t)((maxlen + 15) & ~15);
 	DevBuf& d_min = E->sim_min; DevBuf& d_row = E->sim_row; DevBuf& d_ev = E->sim_ev; DevBuf& d_cnt = E->sim_cnt; DevBuf& d_nodes = E->sim_nodes;
 	int rc = upload(E, d_min, min_scores, sizeof(int64_t) * nrun); if (rc) return rc;
-	const int per_slice = 1024;         // waves in flight: the sweep of one unit takes ~1.5 s of one wave, the chip holds thousands
+	// Units per launch = waves in flight.  The node-list replay is a serial chain per wave, so the chip wants all of its 8192 wave
+	// slots filled (4 units per slice and CU left 3 of 4 SIMD slots idle: 1.7 s per 1024 units, the same for 4096); what limits the
+	// slice is the event scratch (64 row segments of one unit's length = 5 MB per unit): a third of the free HBM at most.
+	int per_slice = 1024;
+	{
+		size_t free_b = 0, total_b = 0;
+		const size_t unit_b = (size_t)64 * cap * sizeof(SimEvent) + (size_t)2 * row_stride * sizeof(uint64_t);
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+			const size_t have = E->sim_ev.cap + free_b / 3;
+			per_slice = (int)std::max<size_t>(256, std::min<size_t>(8192, have / unit_b));
+		}
+		const int nslices = (nrun + per_slice - 1) / per_slice;
+		per_slice = (nrun + nslices - 1) / nslices;           // even slices
+	}
 	std::vector<fasim_sim_node> hn((size_t)per_slice * FASIM_SIM_K);
 	std::vector<int32_t> hc((size_t)per_slice);
 	for (int u0 = 0; u0 < nrun; u0 += per_slice) {
@@ -52,6 +66,143 @@ int sim_forward_units(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, c
 	return FASIM_OK;
 }
 
+// n independent pieces of host work on up to `nthreads` threads
+template <typename F> static void parallel_units(int n, int nthreads, F&& fn)
+{
+	nthreads = std::max(1, std::min(nthreads, n));
+	if (nthreads == 1) { for (int k = 0; k < n; k++) fn(k); return; }
+	std::atomic<int> next(0);
+	std::vector<std::thread> th;
+	for (int t = 0; t < nthreads; t++) th.emplace_back([&]() { for (;;) { const int k = next.fetch_add(1); if (k >= n) break; fn(k); } });
+	for (auto& t : th) t.join();
+}
+
+// ---- row f3: the K rounds of classic SIM after the forward sweep, in lock step over the units [first, first + cnt) of a resident
+// code buffer.  Per round the host threads take each unit's best node, trace its alignment back and build the record
+// (SimUnit::next_round, host_sim.cpp: ~0.6 % of the reference's time in this phase); the re-sweeps of the influenced rectangles
+// (sim.h:884-1141, the other 99 %) are one launch of k_sim_resweep for all units.  The device keeps per unit the DP state per
+// column / row and the used pairs; the node lists travel both ways each round (3.6 KB per unit).
+// FASIM_SIM_RESWEEP=host keeps the re-sweeps on the host threads (A/B); =check runs both and compares every round.
+int sim_resweep_rounds(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, const int32_t* unit_len_dev, const int32_t* unit_len_host,
+	int first, int cnt, SimUnit* const* units, int nthreads)
+{
+	if (cnt <= 0) return FASIM_OK;
+	static const int mode = [] { const char* e = getenv("FASIM_SIM_RESWEEP"); return !e ? 0 : !strcmp(e, "host") ? 1 : !strcmp(e, "check") ? 2 : 0; }();
+	if (mode == 1) {
+		parallel_units(cnt, nthreads, [&](int k) { bool sweep; int box[4]; while (units[k]->next_round(&sweep, box, nullptr)) if (sweep) units[k]->resweep_host(); });
+		return FASIM_OK;
+	}
+	int maxlen = 1;
+	for (int u = 0; u < cnt; u++) maxlen = std::max(maxlen, unit_len_host[first + u]);
+	const int M = E->m;
+	const int64_t col_stride = (maxlen + 2 + 15) & ~15, row_stride = (M + 2 + 15) & ~15;
+	const size_t used_per_unit = (size_t)SIM_K * (size_t)(M + 2) * sizeof(uint16_t);
+	const size_t usedc_per_unit = (size_t)SIM_K * (size_t)col_stride * sizeof(uint16_t);
+	const size_t per_unit = used_per_unit + usedc_per_unit + (size_t)(2 * col_stride + 2 * row_stride) * sizeof(uint64_t);
+	const int slice = (int)std::max<size_t>(1, std::min<size_t>((size_t)cnt, ((size_t)4 << 30) / per_unit));
+	std::vector<SimRoundReq> req((size_t)slice);
+	std::vector<uint32_t> pairs;
+	std::vector<std::vector<std::pair<int, int>>> np((size_t)slice);
+	std::vector<fasim_sim_node> hn((size_t)slice * FASIM_SIM_K);
+	std::vector<int32_t> hc((size_t)slice), hf((size_t)slice), hp((size_t)slice);
+	std::vector<char> pend((size_t)slice);
+	// 64-cell steps per unit and launch: a unit that needs more (a re-sweep of most of the matrix) carries on in the next launch
+	static const int budget = [] { const char* e = getenv("FASIM_SIM_BUDGET"); return e && atoi(e) > 0 ? atoi(e) : 4096; }();
+	static const bool debug = getenv("FASIM_SIM_DEBUG") != nullptr;
+	long launches = 0, unit_launches = 0;
+	if (debug) { HIPOK(E->sim_debug.ensure(64)); HIPOK(hipMemsetAsync(E->sim_debug.p, 0, 64, E->st)); }
+	for (int s0 = 0; s0 < cnt; s0 += slice) {
+		const int n = std::min(slice, cnt - s0);
+		HIPOK(E->sim_used.ensure(used_per_unit * n)); HIPOK(E->sim_rounds.ensure(sizeof(int32_t) * n));
+		HIPOK(E->sim_col.ensure((size_t)n * 2 * col_stride * sizeof(uint64_t))); HIPOK(E->sim_rowst.ensure((size_t)n * 2 * row_stride * sizeof(uint64_t)));
+		HIPOK(E->sim_floor.ensure(sizeof(int32_t) * n)); HIPOK(E->sim_cnt.ensure(sizeof(int32_t) * n));
+		HIPOK(E->sim_nodes.ensure(sizeof(SimNodeDev) * (size_t)n * SIM_K)); HIPOK(E->sim_req.ensure(sizeof(SimRoundReq) * n));
+		HIPOK(hipMemsetAsync(E->sim_used.p, 0, used_per_unit * n, E->st));
+		HIPOK(E->sim_usedc.ensure(usedc_per_unit * n));
+		HIPOK(hipMemsetAsync(E->sim_usedc.p, 0, usedc_per_unit * n, E->st));
+		HIPOK(hipMemsetAsync(E->sim_rounds.p, 0, sizeof(int32_t) * n, E->st));
+		HIPOK(E->sim_pending.ensure(sizeof(int32_t) * n)); HIPOK(E->sim_state.ensure(sizeof(SimSweepState) * n));
+		std::fill(pend.begin(), pend.end(), 0);
+		for (;;) {
+			double t0 = now_s();
+			parallel_units(n, nthreads, [&](int k) {
+				if (pend[(size_t)k]) { req[(size_t)k].active = 2; return; }
+				bool sweep = false; int box[4] = { 0, 0, 0, 0 };
+				SimUnit& U = *units[s0 + k];
+				SimRoundReq r; memset(&r, 0, sizeof r);
+				if (U.next_round(&sweep, box, &np[(size_t)k]) && sweep) {
+					r.active = 1; r.m1 = box[0]; r.mm = box[1]; r.n1 = box[2]; r.nn = box[3]; r.floor_score = (int32_t)U.floor_score;
+				} else np[(size_t)k].clear();
+				req[(size_t)k] = r;
+			});
+			g_prof.add(30, "-F rounds: host half (best node, traceback, record), wall", now_s() - t0);
+			pairs.clear();
+			int active = 0;
+			for (int k = 0; k < n; k++) {
+				SimRoundReq& r = req[(size_t)k];
+				if (!r.active) { hc[(size_t)k] = 0; continue; }
+				active++;
+				if (r.active == 2) continue;                    // its node list is the one the last launch left
+				r.pairs_first = (int32_t)pairs.size(); r.pairs_count = (int32_t)np[(size_t)k].size();
+				for (const auto& pr : np[(size_t)k]) pairs.push_back(((uint32_t)pr.first << 16) | (uint32_t)pr.second);
+				const std::vector<fasim_sim_node>& nl = units[s0 + k]->nodes;
+				hc[(size_t)k] = (int32_t)nl.size();
+				std::copy(nl.begin(), nl.end(), hn.begin() + (size_t)k * FASIM_SIM_K);
+			}
+			if (!active) break;
+			launches++; unit_launches += active;
+			int rc = upload_async(E, E->sim_req, req.data(), sizeof(SimRoundReq) * n); if (rc) return rc;
+			rc = upload_async(E, E->sim_pairs, pairs.data(), sizeof(uint32_t) * pairs.size()); if (rc) return rc;
+			HIPOK(hipMemcpyAsync(E->sim_cnt.p, hc.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, E->st));
+			HIPOK(hipMemcpyAsync(E->sim_nodes.p, hn.data(), sizeof(fasim_sim_node) * (size_t)n * FASIM_SIM_K, hipMemcpyHostToDevice, E->st));
+			SimResweepArgs a;
+			a.tcodes = tcodes_dev + (size_t)(first + s0) * tstride; a.unit_len = unit_len_dev + first + s0; a.tstride = tstride;
+			a.qcodes = E->qsim.as<uint8_t>(); a.m = M;
+			a.req = E->sim_req.as<SimRoundReq>(); a.pairs = E->sim_pairs.as<uint32_t>();
+			a.used = E->sim_used.as<uint16_t>(); a.usedc = E->sim_usedc.as<uint16_t>(); a.used_cnt = E->sim_rounds.as<int32_t>();
+			a.colS = E->sim_col.as<uint64_t>(); a.colG = a.colS + (size_t)n * col_stride;
+			a.rowS = E->sim_rowst.as<uint64_t>(); a.rowG = a.rowS + (size_t)n * row_stride;
+			a.col_stride = col_stride; a.row_stride = row_stride;
+			a.nodes = E->sim_nodes.as<SimNodeDev>(); a.node_count = E->sim_cnt.as<int32_t>(); a.floor_out = E->sim_floor.as<int32_t>();
+			a.pending = E->sim_pending.as<int32_t>(); a.state = E->sim_state.as<SimSweepState>(); a.budget = budget; a.debug = debug ? E->sim_debug.as<uint64_t>() : nullptr;
+			hipError_t he;
+			{ TimedScope ts(E, 7); he = launch_sim_resweep(a, n, E->st); }
+			if (he != hipSuccess) return fail(E, FASIM_E_HIP, "sim_resweep launch failed: %s", hipGetErrorString(he));
+			HIPOK(hipMemcpyAsync(hc.data(), E->sim_cnt.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, E->st));
+			HIPOK(hipMemcpyAsync(hf.data(), E->sim_floor.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, E->st));
+			HIPOK(hipMemcpyAsync(hp.data(), E->sim_pending.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, E->st));
+			HIPOK(hipMemcpyAsync(hn.data(), E->sim_nodes.p, sizeof(fasim_sim_node) * (size_t)n * FASIM_SIM_K, hipMemcpyDeviceToHost, E->st));
+			HIPOK(hipStreamSynchronize(E->st));
+			for (int k = 0; k < n; k++) if (req[(size_t)k].active && (hc[(size_t)k] < 0 || hc[(size_t)k] > FASIM_SIM_K)) return fail(E, FASIM_E_HIP, "sim_resweep: bad node count");
+			for (int k = 0; k < n; k++) pend[(size_t)k] = req[(size_t)k].active && hp[(size_t)k] != 0;
+			if (mode == 2) {
+				std::atomic<int> bad(-1);
+				parallel_units(n, nthreads, [&](int k) {
+					if (!req[(size_t)k].active || pend[(size_t)k]) return;
+					SimUnit& U = *units[s0 + k];
+					const fasim_sim_node* dn = hn.data() + (size_t)k * FASIM_SIM_K;
+					U.resweep_host();
+					if ((int)U.nodes.size() != hc[(size_t)k] || U.floor_score != hf[(size_t)k] || memcmp(U.nodes.data(), dn, sizeof(fasim_sim_node) * U.nodes.size())) bad.store(k);
+				});
+				if (bad.load() >= 0) return fail(E, FASIM_E_HIP, "sim_resweep self-check: unit %d differs from the host re-sweep", first + s0 + bad.load());
+				continue;
+			}
+			for (int k = 0; k < n; k++) {
+				if (!req[(size_t)k].active || pend[(size_t)k]) continue;
+				const fasim_sim_node* dn = hn.data() + (size_t)k * FASIM_SIM_K;
+				units[s0 + k]->nodes.assign(dn, dn + hc[(size_t)k]);
+				units[s0 + k]->floor_score = hf[(size_t)k];
+			}
+		}
+	}
+	if (debug) {
+		uint64_t d[6];
+		HIPOK(hipMemcpy(d, E->sim_debug.p, sizeof d, hipMemcpyDeviceToHost));
+		fprintf(stderr, "[fasim sim] %d units, %ld launches (%ld unit-launches); backward %llu steps %.3f s, forward %llu steps %.3f s of which %llu events %.3f s (wave-seconds)\n",
+			cnt, launches, unit_launches, (unsigned long long)d[0], 1e-8 * (double)d[1], (unsigned long long)d[2], 1e-8 * (double)d[3], (unsigned long long)d[4], 1e-8 * (double)d[5]);
+	}
+	return FASIM_OK;
+}
 
 
 int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t* dna_dev, int64_t shard_lo, int64_t b0, int64_t b1,
@@ -173,36 +324,31 @@ int scan_batch(fasim_engine* E, const char* dna, int64_t dna_len, const uint8_t*
 
 		if (p.classicSim) {
 			// ---- -F: classic SIM instead of fastSIM (Fasim-LongTarget.cpp:420-426): the forward sweep of every unit on the GPU
-			//      (k_sim_forward + node-list replay), traceback / re-sweeps / triplex records on the host threads (host_sim.cpp)
+			//      (k_sim_forward), then K rounds in lock step: traceback + triplex record on the host threads (host_sim.cpp), re-sweeps on the GPU
 			t0 = now_s();
 			std::vector<int64_t> mins((size_t)B.nunit);
 			for (int u = 0; u < B.nunit; u++) mins[(size_t)u] = thr[(size_t)u];
 			std::vector<std::vector<fasim_sim_node>> lists((size_t)B.nunit);
 			std::vector<std::vector<HostTriplex>>& per_unit = C.per_unit;
 			per_unit.assign((size_t)B.nunit, std::vector<HostTriplex>());
-			// the host threads finish the units of a slice while the GPU sweeps the next one
-			std::atomic<int> next(0), ready(0);
-			std::atomic<bool> abort(false);
-			auto work = [&]() {
-				std::string target, src;
-				for (;;) {
-					const int u = next.fetch_add(1);
-					if (u >= B.nunit) break;
-					while (u >= ready.load(std::memory_order_acquire) && !abort.load()) std::this_thread::sleep_for(std::chrono::microseconds(200));
-					if (abort.load()) break;
-					const int s = u / nenc, enc = encs[(size_t)(u % nenc)];
-					encode_unit_host(dna + sidx[(size_t)s] * step, slen[(size_t)s], enc, target, src);
-					sim_finish_unit(E->rna, target, src, (long)(sidx[(size_t)s] * step), thr[(size_t)u], enc, p, lists[(size_t)u], per_unit[(size_t)u]);
-					for (HostTriplex& t : per_unit[(size_t)u]) { t.seg = (int)sidx[(size_t)s]; t.enc = enc; }
-				}
-			};
-			const int nt = std::max(1, std::min(E->sim_threads, B.nunit));
-			std::vector<std::thread> th;
-			for (int k = 0; k < nt; k++) th.emplace_back(work);
-			rc = sim_forward_units(E, E->tcodes.as<uint8_t>(), tstride, E->unit_len.as<int32_t>(), B.unit_len.data(), 0, B.nunit, mins.data(), &ready, lists);
-			if (rc) abort.store(true);
-			for (auto& t : th) t.join();
+			rc = sim_forward_units(E, E->tcodes.as<uint8_t>(), tstride, E->unit_len.as<int32_t>(), B.unit_len.data(), 0, B.nunit, mins.data(), nullptr, lists);
 			if (rc) return rc;
+			std::vector<std::unique_ptr<SimUnit>> units((size_t)B.nunit);
+			parallel_units(B.nunit, E->sim_threads, [&](int u) {
+				std::string target, src;
+				const int s = u / nenc, enc = encs[(size_t)(u % nenc)];
+				encode_unit_host(dna + sidx[(size_t)s] * step, slen[(size_t)s], enc, target, src);
+				units[(size_t)u].reset(new SimUnit(E->rna, target, src, (long)(sidx[(size_t)s] * step), thr[(size_t)u], enc, p, std::move(lists[(size_t)u])));
+			});
+			std::vector<SimUnit*> up((size_t)B.nunit);
+			for (int u = 0; u < B.nunit; u++) up[(size_t)u] = units[(size_t)u].get();
+			rc = sim_resweep_rounds(E, E->tcodes.as<uint8_t>(), tstride, E->unit_len.as<int32_t>(), B.unit_len.data(), 0, B.nunit, up.data(), E->sim_threads);
+			if (rc) return rc;
+			for (int u = 0; u < B.nunit; u++) {
+				const int s = u / nenc, enc = encs[(size_t)(u % nenc)];
+				per_unit[(size_t)u] = std::move(units[(size_t)u]->out);
+				for (HostTriplex& t : per_unit[(size_t)u]) { t.seg = (int)sidx[(size_t)s]; t.enc = enc; }
+			}
 			st.t_stage3_s += now_s() - t0;
 			C.stage3_done = true;
 			return FASIM_OK;

@@ -18,11 +18,12 @@
 //
 // A DP state = one 64-bit key  (score + SIM_BIAS) << 32 | start_row << 16 | start_col,  so ORDER is an unsigned 64-bit max
 // and "score - k" is a subtraction in the top field.  Scores are the reference's x10 values (match 50, mismatch -40, gap
-// open 120, extension 40).  Limits: query and target at most 65535 long (16-bit start fields; 8191 until round 3).
+// open 120, extension 40).  Limits: query and target at most 65534 long (16-bit start fields, and the re-sweep starts lines at row M + 1 / column N + 1; 8191 until round 3).
 // Four units per 256-thread workgroup (one wave each: the waves share nothing).
 // Integer DP: no MFMA.  Plain 64-bit VALU arithmetic, not yet tuned.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "kernels.h"
 
 namespace fasim {
@@ -46,6 +47,137 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l)
 	return ((uint64_t)hi << 32) | lo;
 }
 
+// ---- the node list (sim.h:99-148) in a wave: lane k < cnt holds node k.  addnode: a known start point is updated (a strictly
+// larger score moves the end point; the bounding box grows), a new one is appended or, with K nodes present, overwrites the FIRST
+// node of lowest score whatever its own score is.  In random sequence about a third of all cells are such events (the x10
+// scores are compared with the unscaled threshold, so every isolated match is one), which makes this replay -- serial by
+// definition -- the critical path of both kernels: the lowest score and the lanes that hold it are kept wave-uniform, so an
+// eviction is a count-trailing-zeros, and the wave-wide minimum is only recomputed when that set runs empty.
+struct NodeList {
+	int score, start, endi, endj, top, bot, left, right;      // start = start row << 16 | start column
+	int cnt;                                                  // wave-uniform
+	int low; unsigned long long low_mask;                     // valid while cnt == SIM_K (nodes_add keeps them exact)
+	int junk, l2;                                             // batch path: the first node of lowest score; a lower bound of all other scores
+};
+__device__ __forceinline__ void nodes_find_low(NodeList& L, int lane)
+{
+	unsigned v = lane < L.cnt ? (unsigned)L.score : 0xffffffffu;          // node scores are positive
+	for (int o = 32; o; o >>= 1) { const unsigned w = (unsigned)__shfl_xor((int)v, o, 64); v = w < v ? w : v; }
+	L.low = (int)v;
+	L.low_mask = __ballot(lane < L.cnt && (unsigned)L.score == v);
+}
+__device__ __forceinline__ void nodes_add(NodeList& L, int lane, int c, int start, int ei, int ej)
+{
+	const unsigned long long live = (1ull << L.cnt) - 1;                  // cnt <= SIM_K = 50
+	const unsigned long long same = __ballot(L.start == start) & live;
+	if (same) {
+		const int t = (int)__builtin_ctzll(same);
+		const int old = __builtin_amdgcn_readlane(L.score, t);
+		if (lane == t) {
+			if (L.score < c) { L.score = c; L.endi = ei; L.endj = ej; }
+			L.top = min(L.top, ei); L.bot = max(L.bot, ei); L.left = min(L.left, ej); L.right = max(L.right, ej);
+		}
+		if (old < c && L.cnt == SIM_K && ((L.low_mask >> t) & 1)) { L.low_mask &= ~(1ull << t); if (!L.low_mask) nodes_find_low(L, lane); }
+		return;
+	}
+	int t;
+	if (L.cnt < SIM_K) t = L.cnt++;
+	else t = (int)__builtin_ctzll(L.low_mask);                            // the first node of lowest score gives way (sim.h:129-136)
+	if (lane == t) { L.score = c; L.start = start; L.endi = ei; L.endj = ej; L.top = L.bot = ei; L.left = L.right = ej; }
+	if (L.cnt < SIM_K) return;
+	if (!L.low_mask) { nodes_find_low(L, lane); return; }                 // the list has just become full
+	if (c < L.low) { L.low = c; L.low_mask = 1ull << t; }
+	else if (c > L.low) { L.low_mask &= ~(1ull << t); if (!L.low_mask) nodes_find_low(L, lane); }
+}
+
+// (junk, l2) for the batch path, from an exact (low, low_mask)
+__device__ __forceinline__ void nodes_steady(NodeList& L, int lane)
+{
+	L.junk = -1;
+	if (L.cnt < SIM_K) return;
+	const int t = (int)__builtin_ctzll(L.low_mask);
+	unsigned v = (lane < L.cnt && lane != t) ? (unsigned)L.score : 0xffffffffu;
+	for (int o = 32; o; o >>= 1) { const unsigned w = (unsigned)__shfl_xor((int)v, o, 64); v = w < v ? w : v; }
+	L.junk = t; L.l2 = (int)v;
+}
+
+// Up to 64 events of ONE row in column order (lane order), has = this lane carries one.  With a full list whose first lowest node
+// (`junk`) scores below everything else, an event either belongs to one of the other 49 nodes -- in-place updates, which commute --
+// or it is "junk": it overwrites the junk slot (or continues it, if it has the slot's start point), and as long as it scores below
+// all the others (l2) the slot stays the first lowest node.  Of a batch's junk events only the last run of equal start points
+// leaves a trace, so the batch costs one pass over the 49 start points instead of 64 serial addnode() calls.  Anything else (list
+// not full, a junk event that would outrank another node) takes the serial path for the whole batch.
+__device__ __forceinline__ void nodes_add_batch(NodeList& L, int lane, bool has, int c, int start, int ei, int ej)
+{
+	const unsigned long long evm = __ballot(has);
+	if (!evm) return;
+	if (L.junk >= 0) {
+		const int t = L.junk;
+		int hit = -1;
+		for (int k = 0; k < SIM_K; k++) { const int sk = __builtin_amdgcn_readlane(L.start, k); if (k != t && has && start == sk) hit = k; }
+		const bool junk = has && hit < 0;
+		const unsigned long long jm = __ballot(junk);
+		if (!__ballot(junk && c >= L.l2)) {
+			if (jm) {
+				const int z = 63 - (int)__builtin_clzll(jm);                       // the last junk event and the run of its start point
+				const int sz = __builtin_amdgcn_readlane(start, z);
+				const unsigned long long neq = __ballot(junk && start != sz);
+				const unsigned long long run = neq ? jm & ~((2ull << (63 - (int)__builtin_clzll(neq))) - 1) : jm;
+				const bool continuing = !neq && __builtin_amdgcn_readlane(L.start, t) == sz;
+				int best = -1, bj = 0;
+				for (unsigned long long r = run; r; r &= r - 1) { const int b = (int)__builtin_ctzll(r); const int cb = __builtin_amdgcn_readlane(c, b); if (cb > best) { best = cb; bj = __builtin_amdgcn_readlane(ej, b); } }
+				const int first_j = __builtin_amdgcn_readlane(ej, (int)__builtin_ctzll(run)), last_j = __builtin_amdgcn_readlane(ej, z);
+				if (lane == t) {
+					if (!continuing) { L.score = best; L.start = sz; L.endi = ei; L.endj = bj; L.top = L.bot = ei; L.left = first_j; L.right = last_j; }
+					else {
+						if (L.score < best) { L.score = best; L.endi = ei; L.endj = bj; }
+						L.top = min(L.top, ei); L.bot = max(L.bot, ei); L.left = min(L.left, first_j); L.right = max(L.right, last_j);
+					}
+				}
+			}
+			for (unsigned long long hm = __ballot(hit >= 0); hm;) {
+				const int k = __builtin_amdgcn_readlane(hit, (int)__builtin_ctzll(hm));
+				const unsigned long long mk = __ballot(hit == k);
+				hm &= ~mk;
+				int best = -1, bj = 0;
+				for (unsigned long long r = mk; r; r &= r - 1) { const int b = (int)__builtin_ctzll(r); const int cb = __builtin_amdgcn_readlane(c, b); if (cb > best) { best = cb; bj = __builtin_amdgcn_readlane(ej, b); } }
+				const int first_j = __builtin_amdgcn_readlane(ej, (int)__builtin_ctzll(mk)), last_j = __builtin_amdgcn_readlane(ej, 63 - (int)__builtin_clzll(mk));
+				if (lane == k) {
+					if (L.score < best) { L.score = best; L.endi = ei; L.endj = bj; }
+					L.top = min(L.top, ei); L.bot = max(L.bot, ei); L.left = min(L.left, first_j); L.right = max(L.right, last_j);
+				}
+			}
+			return;
+		}
+		nodes_find_low(L, lane);                  // the batch path does not keep (low, low_mask)
+	}
+	for (unsigned long long r = evm; r; r &= r - 1) {
+		const int b = (int)__builtin_ctzll(r);
+		nodes_add(L, lane, __builtin_amdgcn_readlane(c, b), __builtin_amdgcn_readlane(start, b), ei, __builtin_amdgcn_readlane(ej, b));
+	}
+	nodes_steady(L, lane);
+}
+__device__ __forceinline__ void nodes_load(NodeList& L, int lane, const SimNodeDev* src, int cnt)
+{
+	L.cnt = cnt; L.low = 0; L.low_mask = 0; L.junk = -1; L.l2 = 0;
+	L.score = L.start = L.endi = L.endj = L.top = L.bot = L.left = L.right = 0;
+	if (lane < cnt) {
+		const SimNodeDev nd = src[lane];
+		L.score = (int)nd.score; L.start = (int)((nd.stari << 16) | nd.starj); L.endi = (int)nd.endi; L.endj = (int)nd.endj;
+		L.top = (int)nd.top; L.bot = (int)nd.bot; L.left = (int)nd.left; L.right = (int)nd.right;
+	}
+	if (cnt == SIM_K) { nodes_find_low(L, lane); nodes_steady(L, lane); }
+}
+__device__ __forceinline__ void nodes_store(const NodeList& L, int lane, SimNodeDev* dst)
+{
+	if (lane < L.cnt) {
+		SimNodeDev o;
+		o.score = L.score; o.stari = (L.start >> 16) & 0xffff; o.starj = L.start & 0xffff; o.endi = L.endi; o.endj = L.endj;
+		o.top = L.top; o.bot = L.bot; o.left = L.left; o.right = L.right;
+		dst[lane] = o;
+	}
+}
+
 __global__ void __launch_bounds__(256) k_sim_forward(SimFwdArgs a, int32_t nunit)
 {
 	const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -57,9 +189,8 @@ __global__ void __launch_bounds__(256) k_sim_forward(SimFwdArgs a, int32_t nunit
 	uint64_t* rowC = a.rowbuf + (int64_t)unit * 2 * a.row_stride;      // [0 .. N]: C of the finished strip's bottom row
 	uint64_t* rowD = rowC + a.row_stride;
 	SimEvent* seg = a.events + ((int64_t)unit * 64 + lane) * a.event_cap;      // my row's segment
-	// node list: lane k < nn holds node k
-	int nn = 0;
-	int n_score = 0, n_stari = 0, n_starj = 0, n_endi = 0, n_endj = 0, n_top = 0, n_bot = 0, n_left = 0, n_right = 0;
+	NodeList L;
+	nodes_load(L, lane, nullptr, 0);
 	const int64_t thr = a.min_score[unit];
 	const uint64_t Rk = (uint64_t)SIM_R << SIM_SHIFT, QRk = (uint64_t)(SIM_Q + SIM_R) << SIM_SHIFT;
 	const int nstrips = (M + 63) / 64;
@@ -124,29 +255,8 @@ __global__ void __launch_bounds__(256) k_sim_forward(SimFwdArgs a, int32_t nunit
 				const int nb = min(64, cnt - e0);
 				uint32_t ej = 0, klo = 0, khi = 0;
 				if (lane < nb) { const SimEvent e = rs[e0 + lane]; ej = e.j; klo = (uint32_t)e.key; khi = (uint32_t)(e.key >> 32); }
-				for (int x = 0; x < nb; x++) {
-					const int j = __builtin_amdgcn_readlane((int)ej, x);
-					const uint64_t key = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)khi, x) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)klo, x);
-					const int c = (int)sim_score(key), ci = (int)((key >> SIM_FIELD) & 0xffff), cj = (int)(key & 0xffff);
-					const unsigned long long hit = __ballot(lane < nn && n_stari == ci && n_starj == cj);
-					int target;
-					bool fresh;
-					if (hit) { target = (int)__builtin_ctzll(hit); fresh = false; }
-					else if (nn < SIM_K) { target = nn; nn++; fresh = true; }
-					else {
-						// the first node of lowest score gives way (sim.h:129-136)
-						long long v = lane < SIM_K ? (((long long)n_score << 6) | lane) : 0x7fffffffffffffffll;
-						for (int o = 32; o; o >>= 1) { const long long w = __shfl_xor(v, o, 64); v = w < v ? w : v; }
-						target = (int)(v & 63); fresh = true;
-					}
-					if (lane == target) {
-						if (fresh) { n_score = c; n_stari = ci; n_starj = cj; n_endi = ei; n_endj = j; n_top = n_bot = ei; n_left = n_right = j; }
-						else {
-							if (n_score < c) { n_score = c; n_endi = ei; n_endj = j; }
-							n_top = min(n_top, ei); n_bot = max(n_bot, ei); n_left = min(n_left, j); n_right = max(n_right, j);
-						}
-					}
-				}
+				const uint64_t key = ((uint64_t)khi << 32) | klo;
+				nodes_add_batch(L, lane, lane < nb, (int)sim_score(key), (int)klo, ei, (int)ej);
 			}
 		}
 		// the next strip reads the row buffer this strip has just written (same wave: program order is enough once the
@@ -154,18 +264,295 @@ __global__ void __launch_bounds__(256) k_sim_forward(SimFwdArgs a, int32_t nunit
 		__builtin_amdgcn_s_waitcnt(0);
 		__threadfence_block();
 	}
-	if (lane < nn) {
-		SimNodeDev o;
-		o.score = n_score; o.stari = n_stari; o.starj = n_starj; o.endi = n_endi; o.endj = n_endj; o.top = n_top; o.bot = n_bot; o.left = n_left; o.right = n_right;
-		a.nodes[(int64_t)unit * SIM_K + lane] = o;
+	nodes_store(L, lane, a.nodes + (int64_t)unit * SIM_K);
+	if (lane == 0) a.node_count[unit] = L.cnt;
+}
+
+// ---- the re-sweeps between the K rounds (sim.h:884-1141) ------------------------------------------------------------------
+// After the host has traced a round's alignment back, the rectangle that alignment may have influenced is swept again:
+// backwards from its lower right corner, growing up and to the left one row or one column at a time until no DP state that
+// leaves the rectangle starts inside it and no remaining node crosses it (no_cross, sim.h:150-165), then forwards over the
+// final rectangle, feeding addnode.  One wave per unit; the units of a slice advance in lock step (one launch per round).
+//
+// A sweep line (a query row over target columns, or a target column over query rows) is worked on 64 positions at a time,
+// lane = position.  The states across the line (S = best cell, G = gap entering from beyond the line) are independent per
+// position; the gap ALONG the line is a running maximum of "value at q minus the cost of stretching to t", which with keys is
+// an unsigned 64-bit prefix maximum of (key + R*q) -- six shuffle steps per 64 cells instead of a serial chain.  A cell reached
+// by a gap never re-opens a better gap than the one it came by (Q > 0), so the prefix maximum over the cells' gap-free values
+// is exact, ties included: keys order by (score, start row, start column) like ORDER (sim.h:481-493).
+// The lines' states live in HBM / L2 and are written and read by different lanes of the one wave that owns the unit.  Stores are
+// written through to the XCD's L2 and are complete once the wave's memory counter has drained; loads of them are issued at
+// agent scope, which bypasses the CU's vector L1, so no stale line is ever served.  (A device-scope fence per line would write
+// the whole L2 back each time: measured 300 us per 64 cells with 5 000 waves doing so.)
+__device__ __forceinline__ uint64_t ld_l2(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void wave_publish() { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); }
+
+struct SweepCarry { uint64_t corner, pre; };
+struct SweepCell { uint64_t c, across, g; bool valid; int pos; };
+
+__device__ __forceinline__ uint64_t shfl_up64n(uint64_t v, int d)
+{
+	const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, d, 64), hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d, 64);
+	return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t key_sub(uint64_t k, int64_t s) { return k - ((uint64_t)s << SIM_SHIFT); }
+__device__ __forceinline__ int key_i(uint64_t k) { return (int)((k >> SIM_FIELD) & 0xffff); }
+__device__ __forceinline__ int key_j(uint64_t k) { return (int)(k & 0xffff); }
+
+// 64 cells of a sweep line (sim.h:522-566 and its mirror images): position t0 + lane of n, at index p0 + dir * t.
+// ROW: the line is query row `fix` and positions are target columns; else target column `fix` over query rows.
+template <bool ROW>
+__device__ __forceinline__ SweepCell sweep_chunk(uint64_t* S, uint64_t* G, int p0, int dir, int t0, int n, int fix, uint64_t run0, uint64_t gapf0,
+	SweepCarry& cy, const uint8_t* qcodes, const uint8_t* tcu, int mine, unsigned long long mine_nz, int lane)
+{
+	SweepCell o;
+	const int t = t0 + lane;
+	o.valid = t < n;
+	const int p = p0 + dir * t;
+	o.pos = p;
+	const int i = ROW ? fix : p, j = ROW ? p : fix;
+	const uint64_t oldS = o.valid ? ld_l2(S + p) : 0, oldG = o.valid ? ld_l2(G + p) : 0;
+	uint64_t corner = shfl_up64(oldS);
+	if (lane == 0) corner = cy.corner;
+	cy.corner = readlane64(oldS, 63);
+	o.across = umax64(key_sub(oldG, SIM_R), key_sub(oldS, SIM_Q + SIM_R));
+	int64_t sc = SIM_MISMATCH;
+	bool tk = false;
+	if (o.valid) {
+		const int qc = qcodes[i - 1], tc = tcu[j - 1];
+		if (qc == tc && qc < 4) sc = SIM_MATCH;
 	}
-	if (lane == 0) a.node_count[unit] = nn;
+	// pairs of this line that earlier rounds have aligned (lane e of `mine` = round e's partner of row / column `fix`, 0 = none)
+	for (unsigned long long z = mine_nz; z; z &= z - 1) tk |= __builtin_amdgcn_readlane(mine, (int)__builtin_ctzll(z)) == (ROW ? j : i);
+	const int64_t v = tk ? 0 : sim_score(corner) + sc;
+	const uint64_t c0 = v <= 0 ? sim_key(0, (uint32_t)i, (uint32_t)j) : (uint64_t)((int64_t)corner + (sc << SIM_SHIFT));
+	const uint64_t c1 = umax64(c0, o.across);
+	// gap along the line
+	uint64_t inc = o.valid ? c1 + ((uint64_t)(SIM_R * t) << SIM_SHIFT) : 0;
+	for (int d = 1; d < 64; d <<= 1) { const uint64_t y = shfl_up64n(inc, d); if (lane >= d) inc = umax64(inc, y); }
+	uint64_t exc = shfl_up64(inc);
+	if (lane == 0) exc = 0;
+	exc = umax64(exc, cy.pre);
+	cy.pre = umax64(cy.pre, readlane64(inc, 63));
+	uint64_t g = umax64(key_sub(gapf0, SIM_R * (int64_t)(t + 1)), key_sub(run0, SIM_Q + SIM_R * (int64_t)(t + 1)));
+	if (exc) g = umax64(g, key_sub(exc, SIM_Q + SIM_R * (int64_t)t));
+	o.g = g;
+	o.c = umax64(c1, g);
+	if (o.valid) { S[p] = o.c; G[p] = o.across; }
+	return o;
+}
+
+// A unit's re-sweep is usually a few thousand cells, but now and then (a node that crosses the rectangle) it is the whole matrix:
+// with the units of a slice advancing launch by launch, one such unit would hold up all the others.  So a launch spends at most
+// `budget` 64-cell steps per unit and the kernel is resumable at line boundaries: an unfinished unit saves its loop state
+// (SimSweepState) and carries on in the next launch, while the finished ones go through their next round on the host.
+template <bool LDS>
+__global__ void __launch_bounds__(LDS ? 64 : 256) k_sim_resweep(SimResweepArgs a, int32_t nunit)
+{
+	extern __shared__ uint64_t sim_lds[];
+	const int unit = LDS ? (int)blockIdx.x : (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
+	if (unit >= nunit) return;
+	const int lane = threadIdx.x & 63;
+	const SimRoundReq rq = a.req[unit];
+	if (!rq.active) return;
+	const int M = a.m;
+	const int ustride = M + 2, cstride = (int)a.col_stride;
+	const uint8_t* tcu = a.tcodes + (int64_t)unit * a.tstride;
+	uint16_t* used = a.used + (int64_t)unit * SIM_K * ustride;          // [round][query row] -> target column
+	uint16_t* usedc = a.usedc + (int64_t)unit * SIM_K * cstride;        // [round][target column] -> query row
+	// the lines' states: in LDS when (columns + rows) fit (an LDS access is ~100 cycles, an L2 round trip ~2 us), with a home
+	// in HBM that only an unfinished unit uses, between two launches
+	uint64_t* gCS = a.colS + (int64_t)unit * a.col_stride; uint64_t* gCG = a.colG + (int64_t)unit * a.col_stride;
+	uint64_t* gRS = a.rowS + (int64_t)unit * a.row_stride; uint64_t* gRG = a.rowG + (int64_t)unit * a.row_stride;
+	uint64_t* CS = LDS ? sim_lds : gCS; uint64_t* CG = LDS ? sim_lds + a.col_stride : gCG;
+	uint64_t* RS = LDS ? sim_lds + 2 * a.col_stride : gRS; uint64_t* RG = LDS ? sim_lds + 2 * a.col_stride + a.row_stride : gRG;
+	const int mm = rq.mm, nn = rq.nn;
+	// node list: lane k < cnt holds node k
+	NodeList L;
+	nodes_load(L, lane, a.nodes + (int64_t)unit * SIM_K, a.node_count[unit]);
+	int phase, i, m1, n1, rl, cl, floor_score, nround;
+	bool grow_rows, grow_cols, positive;
+	if (rq.active == 1) {
+		// a new round: its aligned pairs join the rows' lists (slot = round number; at most one pair per row and round)
+		const int round = a.used_cnt[unit];
+		for (int k = lane; k < rq.pairs_count; k += 64) {
+			const uint32_t pr = a.pairs[rq.pairs_first + k];
+			used[(int64_t)round * ustride + (pr >> 16)] = (uint16_t)(pr & 0xffff);
+			usedc[(int64_t)round * cstride + (pr & 0xffff)] = (uint16_t)(pr >> 16);
+		}
+		nround = round + 1;
+		phase = 0; i = mm; m1 = rq.m1; n1 = rq.n1; rl = cl = 0; floor_score = rq.floor_score;
+		grow_rows = grow_cols = true; positive = false;
+		// backwards over the node's rectangle first (sim.h:884-931)
+		for (int j = n1 + lane; j <= nn; j += 64) { CS[j] = sim_key(0, (uint32_t)(mm + 1), (uint32_t)j); CG[j] = sim_key(-SIM_Q, (uint32_t)(mm + 1), (uint32_t)j); }
+		__builtin_amdgcn_s_waitcnt(0);
+		__threadfence();
+	} else {
+		const SimSweepState st = a.state[unit];
+		phase = st.phase; i = st.i; m1 = st.m1; n1 = st.n1; rl = st.rl; cl = st.cl; floor_score = st.floor_score; nround = st.nround;
+		grow_rows = st.grow_rows != 0; grow_cols = st.grow_cols != 0; positive = st.positive != 0;
+		if (LDS) {
+			for (int j = max(n1, 0) + lane; j <= nn; j += 64) { CS[j] = gCS[j]; CG[j] = gCG[j]; }
+			for (int r = max(m1, 0) + lane; r <= mm; r += 64) { RS[r] = gRS[r]; RG[r] = gRG[r]; }
+			wave_publish();
+		}
+	}
+	int budget = a.budget;
+	long long dbg_t[3] = { 0, 0, 0 }, dbg_n[3] = { 0, 0, 0 };      // a.debug: 100 MHz ticks / counts of backward steps, forward steps, events
+
+	auto outside = [&](uint64_t k) { return key_i(k) > rl && key_j(k) > cl; };
+	// one line; returns the last cell's (c, across, gapf); any_out / positive collected over the line
+	struct LineEnd { uint64_t c, d, g; bool any_out; };
+	auto row_line = [&](int r) {
+		LineEnd e; e.any_out = false; e.c = e.d = e.g = 0;
+		const int n = nn - n1 + 1;
+		SweepCarry cy; cy.corner = sim_key(0, (uint32_t)(r + 1), (uint32_t)(nn + 1)); cy.pre = 0;
+		const uint64_t run0 = sim_key(0, (uint32_t)r, (uint32_t)(nn + 1)), gapf0 = sim_key(-SIM_Q, (uint32_t)r, (uint32_t)(nn + 1));
+		bool out = false, pos = false;
+		const int mine = lane < nround ? (int)used[(int64_t)lane * ustride + r] : 0;
+		const unsigned long long mine_nz = __ballot(mine != 0);
+		for (int t0 = 0; t0 < n; t0 += 64) {
+			const SweepCell o = sweep_chunk<true>(CS, CG, nn, -1, t0, n, r, run0, gapf0, cy, a.qcodes, tcu, mine, mine_nz, lane);
+			if (o.valid) { out |= outside(o.c) || outside(o.across) || outside(o.g); pos |= sim_score(o.c) > floor_score; }
+			if (t0 + 64 >= n) { const int l = n - 1 - t0; e.c = readlane64(o.c, l); e.d = readlane64(o.across, l); e.g = readlane64(o.g, l); }
+			budget--;
+		}
+		e.any_out = __ballot(out) != 0;
+		if (__ballot(pos)) positive = true;
+		if (lane == 0) { RS[r] = e.c; RG[r] = e.g; }
+		wave_publish();
+		return e;
+	};
+	auto col_line = [&](int j) {
+		LineEnd e; e.any_out = false; e.c = e.d = e.g = 0;
+		const int n = mm - m1 + 1;
+		SweepCarry cy; cy.corner = sim_key(0, (uint32_t)(mm + 1), (uint32_t)(j + 1)); cy.pre = 0;
+		const uint64_t run0 = sim_key(0, (uint32_t)(mm + 1), (uint32_t)j), gapf0 = sim_key(-SIM_Q, (uint32_t)(mm + 1), (uint32_t)j);
+		bool out = false, pos = false;
+		const int mine = lane < nround ? (int)usedc[(int64_t)lane * cstride + j] : 0;
+		const unsigned long long mine_nz = __ballot(mine != 0);
+		for (int t0 = 0; t0 < n; t0 += 64) {
+			const SweepCell o = sweep_chunk<false>(RS, RG, mm, -1, t0, n, j, run0, gapf0, cy, a.qcodes, tcu, mine, mine_nz, lane);
+			if (o.valid) { out |= outside(o.c) || outside(o.across) || outside(o.g); pos |= sim_score(o.c) > floor_score; }
+			if (t0 + 64 >= n) { const int l = n - 1 - t0; e.c = readlane64(o.c, l); e.d = readlane64(o.across, l); e.g = readlane64(o.g, l); }
+			budget--;
+		}
+		e.any_out = __ballot(out) != 0;
+		if (__ballot(pos)) positive = true;
+		if (lane == 0) { CS[j] = e.c; CG[j] = e.g; }
+		wave_publish();
+		return e;
+	};
+
+	const int budget0 = budget;
+	long long tick = a.debug ? (long long)wall_clock64() : 0;
+	// ---- phase 0: backwards over the node's rectangle
+	if (phase == 0) {
+		while (i >= m1 && budget > 0) { row_line(i); i--; }
+		if (i < m1) { phase = 1; rl = m1; cl = n1; grow_rows = grow_cols = true; }
+	}
+	// ---- phase 1: growth (sim.h:933-1084): rl / cl = the smallest start row / column a state may have without leaving
+	while (phase == 1 && budget > 0) {
+		if ((grow_rows && m1 > 1) || (grow_cols && n1 > 1)) {
+			if (grow_rows && m1 > 1) {
+				m1--;
+				const LineEnd e = row_line(m1);
+				grow_rows = e.any_out;
+				if (!grow_cols && (outside(e.c) || outside(e.d) || outside(e.g))) grow_cols = true;
+			}
+			if (grow_cols && n1 > 1) {
+				n1--;
+				const LineEnd e = col_line(n1);
+				grow_cols = e.any_out;
+				if (!grow_rows && (outside(e.c) || outside(e.d) || outside(e.g))) grow_rows = true;
+			}
+			continue;
+		}
+		bool grown = m1 == 1 && n1 == 1;
+		if (!grown) {
+			// no_cross (sim.h:150-165): the first node whose alignments may reach into the rectangle from outside
+			const int n_stari = (L.start >> 16) & 0xffff, n_starj = L.start & 0xffff;
+			const unsigned long long hit = __ballot(lane < L.cnt && n_stari <= mm && n_starj <= nn && L.bot >= m1 - 1 && L.right >= n1 - 1 && (n_stari < rl || n_starj < cl));
+			if (!hit) grown = true;
+			else {
+				const int f = (int)__builtin_ctzll(hit);
+				const int si = __builtin_amdgcn_readlane(n_stari, f), sj = __builtin_amdgcn_readlane(n_starj, f);
+				if (si < rl) rl = si;
+				if (sj < cl) cl = sj;
+				grow_rows = grow_cols = true;
+			}
+		}
+		if (grown) {
+			m1--; n1--;
+			if (positive) {
+				phase = 2; i = m1 + 1;
+				for (int j = n1 + 1 + lane; j <= nn; j += 64) { CS[j] = sim_key(0, (uint32_t)m1, (uint32_t)j); CG[j] = sim_key(-SIM_Q, (uint32_t)m1, (uint32_t)j); }
+				wave_publish();
+			} else phase = 3;
+		}
+	}
+	if (a.debug) { const long long now = (long long)wall_clock64(); dbg_t[0] = now - tick; dbg_n[0] = budget0 - budget; tick = now; }
+	const int budget1 = budget;
+	// ---- phase 2: forwards over the final rectangle, new nodes in row-major order (sim.h:1086-1141)
+	if (phase == 2) {
+		const int n = nn - n1;
+		for (; i <= mm && budget > 0; i++) {
+			SweepCarry cy; cy.corner = sim_key(0, (uint32_t)(i - 1), (uint32_t)n1); cy.pre = 0;
+			const uint64_t run0 = sim_key(0, (uint32_t)i, (uint32_t)n1), gapf0 = sim_key(-SIM_Q, (uint32_t)i, (uint32_t)n1);
+			const int mine = lane < nround ? (int)used[(int64_t)lane * ustride + i] : 0;
+			const unsigned long long mine_nz = __ballot(mine != 0);
+			for (int t0 = 0; t0 < n; t0 += 64) {
+				const SweepCell o = sweep_chunk<true>(CS, CG, n1 + 1, 1, t0, n, i, run0, gapf0, cy, a.qcodes, tcu, mine, mine_nz, lane);
+				budget--;
+				unsigned long long ev = __ballot(o.valid && sim_score(o.c) > floor_score);
+				if (ev) floor_score = 1;                         // min = addnode() (sim.h:1131): 1 from the first new cell on
+				const long long te = a.debug ? (long long)wall_clock64() : 0;
+				dbg_n[2] += __builtin_popcountll(ev);
+				nodes_add_batch(L, lane, (ev >> lane) & 1, (int)sim_score(o.c), (int)(uint32_t)o.c, i, n1 + 1 + t0 + lane);
+				if (a.debug) dbg_t[2] += (long long)wall_clock64() - te;
+			}
+			wave_publish();
+		}
+		if (i > mm) phase = 3;
+	}
+	if (a.debug && lane == 0) {
+		dbg_t[1] = (long long)wall_clock64() - tick; dbg_n[1] = budget1 - budget;
+		for (int k = 0; k < 3; k++) { atomicAdd((unsigned long long*)a.debug + 2 * k, (unsigned long long)dbg_n[k]); atomicAdd((unsigned long long*)a.debug + 2 * k + 1, (unsigned long long)dbg_t[k]); }
+	}
+	nodes_store(L, lane, a.nodes + (int64_t)unit * SIM_K);
+	if (lane == 0) {
+		a.node_count[unit] = L.cnt; a.floor_out[unit] = floor_score; a.used_cnt[unit] = nround; a.pending[unit] = phase != 3;
+		if (phase != 3) {
+			SimSweepState st;
+			st.phase = phase; st.i = i; st.m1 = m1; st.n1 = n1; st.rl = rl; st.cl = cl; st.floor_score = floor_score; st.nround = nround;
+			st.grow_rows = grow_rows; st.grow_cols = grow_cols; st.positive = positive;
+			a.state[unit] = st;
+		}
+	}
+	if (LDS && phase != 3) {
+		for (int j = max(n1, 0) + lane; j <= nn; j += 64) { gCS[j] = CS[j]; gCG[j] = CG[j]; }
+		for (int r = max(m1, 0) + lane; r <= mm; r += 64) { gRS[r] = RS[r]; gRG[r] = RG[r]; }
+	}
 }
 
 hipError_t launch_sim_forward(const SimFwdArgs& a, int32_t nunit, hipStream_t st)
 {
 	if (nunit <= 0) return hipSuccess;
 	hipLaunchKernelGGL(k_sim_forward, dim3((unsigned)((nunit + 3) / 4)), dim3(256), 0, st, a, nunit);
+	return hipGetLastError();
+}
+
+hipError_t launch_sim_resweep(const SimResweepArgs& a, int32_t nunit, hipStream_t st)
+{
+	if (nunit <= 0) return hipSuccess;
+	// the lines' states of one unit: 16 B per target column and per query row; in LDS when that fits one CU's 160 KB (minus a margin)
+	const size_t lds = (size_t)(2 * a.col_stride + 2 * a.row_stride) * sizeof(uint64_t);
+	static const bool want_lds = [] { const char* e = getenv("FASIM_SIM_LDS"); return e ? atoi(e) != 0 : true; }();
+	if (want_lds && lds <= 150 * 1024) {
+		static bool attr_set = false;
+		if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_sim_resweep<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+		hipLaunchKernelGGL(k_sim_resweep<true>, dim3((unsigned)nunit), dim3(64), lds, st, a, nunit);
+	} else hipLaunchKernelGGL(k_sim_resweep<false>, dim3((unsigned)((nunit + 3) / 4)), dim3(256), 0, st, a, nunit);
 	return hipGetLastError();
 }
 
