@@ -100,6 +100,7 @@ void fasim_engine_destroy(fasim_engine* e)
 	for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
 	for (DevBuf* b : bufs) b->release();
 	if (e->pin_dna) (void)hipHostFree(e->pin_dna);
+	if (e->pin_sim) (void)hipHostFree(e->pin_sim);
 	if (e->st) (void)hipStreamDestroy(e->st);
 	delete e;
 }

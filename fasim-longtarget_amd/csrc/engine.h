@@ -115,6 +115,7 @@ struct fasim_engine {
 	DevBuf dna_res;
 	// streaming ingest (fasim_scan with a host buffer): pinned staging buffer of this worker's current batch slice
 	void* pin_dna = nullptr; size_t pin_cap = 0;
+	void* pin_sim = nullptr; size_t pin_sim_cap = 0;     // -F: node lists of a slice, both ways every launch
 	// HIP-event timing of kernel launches on `st`
 	struct Timed { hipEvent_t a, b; int family; };
 	std::vector<Timed> timed;

@@ -87,7 +87,8 @@ int sim_resweep_rounds(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, 
 	int first, int cnt, SimUnit* const* units, int nthreads)
 {
 	if (cnt <= 0) return FASIM_OK;
-	static const int mode = [] { const char* e = getenv("FASIM_SIM_RESWEEP"); return !e ? 0 : !strcmp(e, "host") ? 1 : !strcmp(e, "check") ? 2 : 0; }();
+	const char* mode_env = getenv("FASIM_SIM_RESWEEP");      // read per call: the tests switch it
+	const int mode = !mode_env ? 0 : !strcmp(mode_env, "host") ? 1 : !strcmp(mode_env, "check") ? 2 : 0;
 	if (mode == 1) {
 		parallel_units(cnt, nthreads, [&](int k) { bool sweep; int box[4]; while (units[k]->next_round(&sweep, box, nullptr)) if (sweep) units[k]->resweep_host(); });
 		return FASIM_OK;
@@ -103,14 +104,23 @@ int sim_resweep_rounds(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, 
 	std::vector<SimRoundReq> req((size_t)slice);
 	std::vector<uint32_t> pairs;
 	std::vector<std::vector<std::pair<int, int>>> np((size_t)slice);
-	std::vector<fasim_sim_node> hn((size_t)slice * FASIM_SIM_K);
+	// node lists both ways every launch (3.6 KB per unit): pinned, or the copies are staged at a few GB/s
+	const size_t hn_bytes = sizeof(fasim_sim_node) * (size_t)slice * FASIM_SIM_K;
+	if (hn_bytes > E->pin_sim_cap) {
+		if (E->pin_sim) { (void)hipHostFree(E->pin_sim); E->pin_sim = nullptr; E->pin_sim_cap = 0; }
+		HIPOK(hipHostMalloc(&E->pin_sim, hn_bytes, hipHostMallocDefault));
+		E->pin_sim_cap = hn_bytes;
+	}
+	fasim_sim_node* const hn = (fasim_sim_node*)E->pin_sim;
 	std::vector<int32_t> hc((size_t)slice), hf((size_t)slice), hp((size_t)slice);
 	std::vector<char> pend((size_t)slice);
-	// 64-cell steps per unit and launch: a unit that needs more (a re-sweep of most of the matrix) carries on in the next launch
-	static const int budget = [] { const char* e = getenv("FASIM_SIM_BUDGET"); return e && atoi(e) > 0 ? atoi(e) : 4096; }();
+	// 64-cell steps per unit and launch: a unit that needs more (a re-sweep of most of the matrix) carries on in the next launch.
+	// The average round of H19 x 5 kb takes 10 k steps, the heaviest unit of a 500 kb record 12 M steps in all.
+	const char* budget_s = getenv("FASIM_SIM_BUDGET");       // (tests: a small budget exercises suspend / resume)
+	const int budget_env = budget_s && atoi(budget_s) > 0 ? atoi(budget_s) : 0;
 	static const bool debug = getenv("FASIM_SIM_DEBUG") != nullptr;
 	long launches = 0, unit_launches = 0;
-	if (debug) { HIPOK(E->sim_debug.ensure(64)); HIPOK(hipMemsetAsync(E->sim_debug.p, 0, 64, E->st)); }
+	if (debug) { HIPOK(E->sim_debug.ensure(128)); HIPOK(hipMemsetAsync(E->sim_debug.p, 0, 128, E->st)); }
 	for (int s0 = 0; s0 < cnt; s0 += slice) {
 		const int n = std::min(slice, cnt - s0);
 		HIPOK(E->sim_used.ensure(used_per_unit * n)); HIPOK(E->sim_rounds.ensure(sizeof(int32_t) * n));
@@ -147,14 +157,14 @@ int sim_resweep_rounds(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, 
 				for (const auto& pr : np[(size_t)k]) pairs.push_back(((uint32_t)pr.first << 16) | (uint32_t)pr.second);
 				const std::vector<fasim_sim_node>& nl = units[s0 + k]->nodes;
 				hc[(size_t)k] = (int32_t)nl.size();
-				std::copy(nl.begin(), nl.end(), hn.begin() + (size_t)k * FASIM_SIM_K);
+				std::copy(nl.begin(), nl.end(), hn + (size_t)k * FASIM_SIM_K);
 			}
 			if (!active) break;
 			launches++; unit_launches += active;
 			int rc = upload_async(E, E->sim_req, req.data(), sizeof(SimRoundReq) * n); if (rc) return rc;
 			rc = upload_async(E, E->sim_pairs, pairs.data(), sizeof(uint32_t) * pairs.size()); if (rc) return rc;
 			HIPOK(hipMemcpyAsync(E->sim_cnt.p, hc.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, E->st));
-			HIPOK(hipMemcpyAsync(E->sim_nodes.p, hn.data(), sizeof(fasim_sim_node) * (size_t)n * FASIM_SIM_K, hipMemcpyHostToDevice, E->st));
+			HIPOK(hipMemcpyAsync(E->sim_nodes.p, hn, sizeof(fasim_sim_node) * (size_t)n * FASIM_SIM_K, hipMemcpyHostToDevice, E->st));
 			SimResweepArgs a;
 			a.tcodes = tcodes_dev + (size_t)(first + s0) * tstride; a.unit_len = unit_len_dev + first + s0; a.tstride = tstride;
 			a.qcodes = E->qsim.as<uint8_t>(); a.m = M;
@@ -164,14 +174,14 @@ int sim_resweep_rounds(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, 
 			a.rowS = E->sim_rowst.as<uint64_t>(); a.rowG = a.rowS + (size_t)n * row_stride;
 			a.col_stride = col_stride; a.row_stride = row_stride;
 			a.nodes = E->sim_nodes.as<SimNodeDev>(); a.node_count = E->sim_cnt.as<int32_t>(); a.floor_out = E->sim_floor.as<int32_t>();
-			a.pending = E->sim_pending.as<int32_t>(); a.state = E->sim_state.as<SimSweepState>(); a.budget = budget; a.debug = debug ? E->sim_debug.as<uint64_t>() : nullptr;
+			a.pending = E->sim_pending.as<int32_t>(); a.state = E->sim_state.as<SimSweepState>(); a.budget = budget_env ? budget_env : (active > 1024 ? 16384 : 65536); a.debug = debug ? E->sim_debug.as<uint64_t>() : nullptr;
 			hipError_t he;
-			{ TimedScope ts(E, 7); he = launch_sim_resweep(a, n, E->st); }
+			{ TimedScope ts(E, 7); he = launch_sim_resweep(a, n, active <= 512, E->st); }
 			if (he != hipSuccess) return fail(E, FASIM_E_HIP, "sim_resweep launch failed: %s", hipGetErrorString(he));
 			HIPOK(hipMemcpyAsync(hc.data(), E->sim_cnt.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, E->st));
 			HIPOK(hipMemcpyAsync(hf.data(), E->sim_floor.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, E->st));
 			HIPOK(hipMemcpyAsync(hp.data(), E->sim_pending.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, E->st));
-			HIPOK(hipMemcpyAsync(hn.data(), E->sim_nodes.p, sizeof(fasim_sim_node) * (size_t)n * FASIM_SIM_K, hipMemcpyDeviceToHost, E->st));
+			HIPOK(hipMemcpyAsync(hn, E->sim_nodes.p, sizeof(fasim_sim_node) * (size_t)n * FASIM_SIM_K, hipMemcpyDeviceToHost, E->st));
 			HIPOK(hipStreamSynchronize(E->st));
 			for (int k = 0; k < n; k++) if (req[(size_t)k].active && (hc[(size_t)k] < 0 || hc[(size_t)k] > FASIM_SIM_K)) return fail(E, FASIM_E_HIP, "sim_resweep: bad node count");
 			for (int k = 0; k < n; k++) pend[(size_t)k] = req[(size_t)k].active && hp[(size_t)k] != 0;
@@ -180,7 +190,7 @@ int sim_resweep_rounds(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, 
 				parallel_units(n, nthreads, [&](int k) {
 					if (!req[(size_t)k].active || pend[(size_t)k]) return;
 					SimUnit& U = *units[s0 + k];
-					const fasim_sim_node* dn = hn.data() + (size_t)k * FASIM_SIM_K;
+					const fasim_sim_node* dn = hn + (size_t)k * FASIM_SIM_K;
 					U.resweep_host();
 					if ((int)U.nodes.size() != hc[(size_t)k] || U.floor_score != hf[(size_t)k] || memcmp(U.nodes.data(), dn, sizeof(fasim_sim_node) * U.nodes.size())) bad.store(k);
 				});
@@ -189,17 +199,17 @@ int sim_resweep_rounds(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, 
 			}
 			for (int k = 0; k < n; k++) {
 				if (!req[(size_t)k].active || pend[(size_t)k]) continue;
-				const fasim_sim_node* dn = hn.data() + (size_t)k * FASIM_SIM_K;
+				const fasim_sim_node* dn = hn + (size_t)k * FASIM_SIM_K;
 				units[s0 + k]->nodes.assign(dn, dn + hc[(size_t)k]);
 				units[s0 + k]->floor_score = hf[(size_t)k];
 			}
 		}
 	}
 	if (debug) {
-		uint64_t d[6];
+		uint64_t d[11];
 		HIPOK(hipMemcpy(d, E->sim_debug.p, sizeof d, hipMemcpyDeviceToHost));
-		fprintf(stderr, "[fasim sim] %d units, %ld launches (%ld unit-launches); backward %llu steps %.3f s, forward %llu steps %.3f s of which %llu events %.3f s (wave-seconds)\n",
-			cnt, launches, unit_launches, (unsigned long long)d[0], 1e-8 * (double)d[1], (unsigned long long)d[2], 1e-8 * (double)d[3], (unsigned long long)d[4], 1e-8 * (double)d[5]);
+		fprintf(stderr, "[fasim sim] %d units, %ld launches (%ld unit-launches); backward %llu steps %.3f s, forward %llu steps %.3f s of which %llu events %.3f s (wave-seconds); replay passes %llu, outranking events %llu, solid hits %llu; hit loop %.3f s, junk run %.3f s, solid updates %.3f s\n",
+			cnt, launches, unit_launches, (unsigned long long)d[0], 1e-8 * (double)d[1], (unsigned long long)d[2], 1e-8 * (double)d[3], (unsigned long long)d[4], 1e-8 * (double)d[5], (unsigned long long)d[6], (unsigned long long)(d[7] & 0xffffffffu), (unsigned long long)(d[7] >> 32), 1e-8 * (double)d[8], 1e-8 * (double)d[9], 1e-8 * (double)d[10]);
 	}
 	return FASIM_OK;
 }

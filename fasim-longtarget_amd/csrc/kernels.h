@@ -147,6 +147,6 @@ hipError_t launch_align_band(const BandLaunch& L, hipStream_t st);
 
 // ---- sim.hip: forward sweep of classic SIM (-F), one wave per unit ---------------------------------------
 hipError_t launch_sim_forward(const SimFwdArgs& a, int32_t nunit, hipStream_t st);
-hipError_t launch_sim_resweep(const SimResweepArgs& a, int32_t nunit, hipStream_t st);
+hipError_t launch_sim_resweep(const SimResweepArgs& a, int32_t nunit, bool few_units, hipStream_t st);
 
 } // namespace fasim

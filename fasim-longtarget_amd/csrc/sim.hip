@@ -47,6 +47,37 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l)
 	return ((uint64_t)hi << 32) | lo;
 }
 
+// DPP forms (no LDS crossbar round trip): value of lane - 1 (0 into lane 0), inclusive prefix maximum, wave maximum
+#define SIM_DPP(old, v, ctrl, rows) __builtin_amdgcn_update_dpp((int)(old), (int)(v), (ctrl), (rows), 0xf, false)
+__device__ __forceinline__ uint64_t dpp_up64(uint64_t v)
+{
+	const uint32_t lo = (uint32_t)SIM_DPP(0, (uint32_t)v, 0x138 /* wave_shr:1 */, 0xf), hi = (uint32_t)SIM_DPP(0, (uint32_t)(v >> 32), 0x138, 0xf);
+	return ((uint64_t)hi << 32) | lo;
+}
+template <int CTRL, int ROWS> __device__ __forceinline__ uint64_t dpp_max64_step(uint64_t v)
+{
+	const uint32_t lo = (uint32_t)SIM_DPP(0, (uint32_t)v, CTRL, ROWS), hi = (uint32_t)SIM_DPP(0, (uint32_t)(v >> 32), CTRL, ROWS);
+	return umax64(v, ((uint64_t)hi << 32) | lo);          // lanes without a source see 0: keys are positive
+}
+__device__ __forceinline__ uint64_t prefix_max64(uint64_t v)
+{
+	v = dpp_max64_step<0x111, 0xf>(v);      // row_shr:1, 2, 4, 8: inclusive scan of each row of 16
+	v = dpp_max64_step<0x112, 0xf>(v);
+	v = dpp_max64_step<0x114, 0xf>(v);
+	v = dpp_max64_step<0x118, 0xf>(v);
+	v = dpp_max64_step<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+	v = dpp_max64_step<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3
+	return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+	const int lowest = (int)0x80000000;
+	v = max(v, SIM_DPP(lowest, v, 0x111, 0xf)); v = max(v, SIM_DPP(lowest, v, 0x112, 0xf));
+	v = max(v, SIM_DPP(lowest, v, 0x114, 0xf)); v = max(v, SIM_DPP(lowest, v, 0x118, 0xf));
+	v = max(v, SIM_DPP(lowest, v, 0x142, 0xa)); v = max(v, SIM_DPP(lowest, v, 0x143, 0xc));
+	return __builtin_amdgcn_readlane(v, 63);
+}
+
 // ---- the node list (sim.h:99-148) in a wave: lane k < cnt holds node k.  addnode: a known start point is updated (a strictly
 // larger score moves the end point; the bounding box grows), a new one is appended or, with K nodes present, overwrites the FIRST
 // node of lowest score whatever its own score is.  In random sequence about a third of all cells are such events (the x10
@@ -58,6 +89,8 @@ struct NodeList {
 	int cnt;                                                  // wave-uniform
 	int low; unsigned long long low_mask;                     // valid while cnt == SIM_K (nodes_add keeps them exact)
 	int junk, l2;                                             // batch path: the first node of lowest score; a lower bound of all other scores
+	int dbg_pass, dbg_bad, dbg_serial;                        // FASIM_SIM_DEBUG counters
+	long long dbg_t0, dbg_t1, dbg_t2;
 };
 __device__ __forceinline__ void nodes_find_low(NodeList& L, int lane)
 {
@@ -109,57 +142,83 @@ __device__ __forceinline__ void nodes_steady(NodeList& L, int lane)
 // not full, a junk event that would outrank another node) takes the serial path for the whole batch.
 __device__ __forceinline__ void nodes_add_batch(NodeList& L, int lane, bool has, int c, int start, int ei, int ej)
 {
-	const unsigned long long evm = __ballot(has);
-	if (!evm) return;
-	if (L.junk >= 0) {
+	unsigned long long todo = __ballot(has);
+	while (todo) {
+		if (L.junk < 0) {
+			// list not full yet: one event at a time
+			const int b = (int)__builtin_ctzll(todo);
+			todo &= todo - 1;
+			L.dbg_serial++;
+			nodes_add(L, lane, __builtin_amdgcn_readlane(c, b), __builtin_amdgcn_readlane(start, b), ei, __builtin_amdgcn_readlane(ej, b));
+			if (L.cnt == SIM_K) nodes_steady(L, lane);
+			continue;
+		}
 		const int t = L.junk;
+		L.dbg_pass++;
+		const long long tq0 = (long long)wall_clock64();
+		const bool mine = (todo >> lane) & 1;
 		int hit = -1;
-		for (int k = 0; k < SIM_K; k++) { const int sk = __builtin_amdgcn_readlane(L.start, k); if (k != t && has && start == sk) hit = k; }
-		const bool junk = has && hit < 0;
+		{
+			const int others = lane == t ? -1 : L.start;                // -1 is no start point (rows and columns stay below 65535)
+#pragma unroll
+			for (int k = 0; k < SIM_K; k++) { const int sk = __builtin_amdgcn_readlane(others, k); hit = start == sk ? k : hit; }
+			hit = mine ? hit : -1;
+		}
+		// the batch path takes the events before the first junk event that would outrank another node; that one goes through
+		// addnode() on its own, after which the roles (junk slot, l2) are worked out again for the rest
+		const unsigned long long bad = __ballot(mine && hit < 0 && c >= L.l2);
+		const unsigned long long part = bad ? todo & ((1ull << (int)__builtin_ctzll(bad)) - 1) : todo;
+		const bool now = (part >> lane) & 1;
+		const bool junk = now && hit < 0;
 		const unsigned long long jm = __ballot(junk);
-		if (!__ballot(junk && c >= L.l2)) {
-			if (jm) {
-				const int z = 63 - (int)__builtin_clzll(jm);                       // the last junk event and the run of its start point
-				const int sz = __builtin_amdgcn_readlane(start, z);
-				const unsigned long long neq = __ballot(junk && start != sz);
-				const unsigned long long run = neq ? jm & ~((2ull << (63 - (int)__builtin_clzll(neq))) - 1) : jm;
-				const bool continuing = !neq && __builtin_amdgcn_readlane(L.start, t) == sz;
-				int best = -1, bj = 0;
-				for (unsigned long long r = run; r; r &= r - 1) { const int b = (int)__builtin_ctzll(r); const int cb = __builtin_amdgcn_readlane(c, b); if (cb > best) { best = cb; bj = __builtin_amdgcn_readlane(ej, b); } }
-				const int first_j = __builtin_amdgcn_readlane(ej, (int)__builtin_ctzll(run)), last_j = __builtin_amdgcn_readlane(ej, z);
-				if (lane == t) {
-					if (!continuing) { L.score = best; L.start = sz; L.endi = ei; L.endj = bj; L.top = L.bot = ei; L.left = first_j; L.right = last_j; }
-					else {
-						if (L.score < best) { L.score = best; L.endi = ei; L.endj = bj; }
-						L.top = min(L.top, ei); L.bot = max(L.bot, ei); L.left = min(L.left, first_j); L.right = max(L.right, last_j);
-					}
-				}
-			}
-			for (unsigned long long hm = __ballot(hit >= 0); hm;) {
-				const int k = __builtin_amdgcn_readlane(hit, (int)__builtin_ctzll(hm));
-				const unsigned long long mk = __ballot(hit == k);
-				hm &= ~mk;
-				int best = -1, bj = 0;
-				for (unsigned long long r = mk; r; r &= r - 1) { const int b = (int)__builtin_ctzll(r); const int cb = __builtin_amdgcn_readlane(c, b); if (cb > best) { best = cb; bj = __builtin_amdgcn_readlane(ej, b); } }
-				const int first_j = __builtin_amdgcn_readlane(ej, (int)__builtin_ctzll(mk)), last_j = __builtin_amdgcn_readlane(ej, 63 - (int)__builtin_clzll(mk));
-				if (lane == k) {
+		const long long tq1 = (long long)wall_clock64();
+		if (jm) {
+			const int z = 63 - (int)__builtin_clzll(jm);                       // the last junk event and the run of its start point
+			const int sz = __builtin_amdgcn_readlane(start, z);
+			const unsigned long long neq = __ballot(junk && start != sz);
+			const unsigned long long run = neq ? jm & ~((2ull << (63 - (int)__builtin_clzll(neq))) - 1) : jm;
+			const bool continuing = !neq && __builtin_amdgcn_readlane(L.start, t) == sz;
+			int best = -1, bj = 0;
+			for (unsigned long long r = run; r; r &= r - 1) { const int b = (int)__builtin_ctzll(r); const int cb = __builtin_amdgcn_readlane(c, b); if (cb > best) { best = cb; bj = __builtin_amdgcn_readlane(ej, b); } }
+			const int first_j = __builtin_amdgcn_readlane(ej, (int)__builtin_ctzll(run)), last_j = __builtin_amdgcn_readlane(ej, z);
+			if (lane == t) {
+				if (!continuing) { L.score = best; L.start = sz; L.endi = ei; L.endj = bj; L.top = L.bot = ei; L.left = first_j; L.right = last_j; }
+				else {
 					if (L.score < best) { L.score = best; L.endi = ei; L.endj = bj; }
 					L.top = min(L.top, ei); L.bot = max(L.bot, ei); L.left = min(L.left, first_j); L.right = max(L.right, last_j);
 				}
 			}
-			return;
 		}
-		nodes_find_low(L, lane);                  // the batch path does not keep (low, low_mask)
+		const long long tq2 = (long long)wall_clock64();
+		L.dbg_t0 += tq1 - tq0; L.dbg_t1 += tq2 - tq1; L.dbg_serial += __builtin_popcountll(__ballot(now && hit >= 0));
+		for (unsigned long long hm = __ballot(now && hit >= 0); hm;) {
+			const int k = __builtin_amdgcn_readlane(hit, (int)__builtin_ctzll(hm));
+			const unsigned long long mk = __ballot(now && hit == k);
+			hm &= ~mk;
+			const bool in = (mk >> lane) & 1;
+			const int best = wave_max_i32(in ? c : -1);
+			const int bj = __builtin_amdgcn_readlane(ej, (int)__builtin_ctzll(__ballot(in && c == best)));     // the first event that reaches it
+			const int first_j = __builtin_amdgcn_readlane(ej, (int)__builtin_ctzll(mk)), last_j = __builtin_amdgcn_readlane(ej, 63 - (int)__builtin_clzll(mk));
+			if (lane == k) {
+				if (L.score < best) { L.score = best; L.endi = ei; L.endj = bj; }
+				L.top = min(L.top, ei); L.bot = max(L.bot, ei); L.left = min(L.left, first_j); L.right = max(L.right, last_j);
+			}
+		}
+		L.dbg_t2 += (long long)wall_clock64() - tq2;
+		todo &= ~part;
+		if (bad) {
+			const int b = (int)__builtin_ctzll(bad);
+			todo &= ~(1ull << b);
+			L.dbg_bad++;
+			nodes_find_low(L, lane);                  // the batch path does not keep (low, low_mask)
+			nodes_add(L, lane, __builtin_amdgcn_readlane(c, b), __builtin_amdgcn_readlane(start, b), ei, __builtin_amdgcn_readlane(ej, b));
+			nodes_steady(L, lane);
+		}
 	}
-	for (unsigned long long r = evm; r; r &= r - 1) {
-		const int b = (int)__builtin_ctzll(r);
-		nodes_add(L, lane, __builtin_amdgcn_readlane(c, b), __builtin_amdgcn_readlane(start, b), ei, __builtin_amdgcn_readlane(ej, b));
-	}
-	nodes_steady(L, lane);
 }
 __device__ __forceinline__ void nodes_load(NodeList& L, int lane, const SimNodeDev* src, int cnt)
 {
-	L.cnt = cnt; L.low = 0; L.low_mask = 0; L.junk = -1; L.l2 = 0;
+	L.cnt = cnt; L.low = 0; L.low_mask = 0; L.junk = -1; L.l2 = 0; L.dbg_pass = L.dbg_bad = L.dbg_serial = 0; L.dbg_t0 = L.dbg_t1 = L.dbg_t2 = 0;
 	L.score = L.start = L.endi = L.endj = L.top = L.bot = L.left = L.right = 0;
 	if (lane < cnt) {
 		const SimNodeDev nd = src[lane];
@@ -312,7 +371,7 @@ __device__ __forceinline__ SweepCell sweep_chunk(uint64_t* S, uint64_t* G, int p
 	o.pos = p;
 	const int i = ROW ? fix : p, j = ROW ? p : fix;
 	const uint64_t oldS = o.valid ? ld_l2(S + p) : 0, oldG = o.valid ? ld_l2(G + p) : 0;
-	uint64_t corner = shfl_up64(oldS);
+	uint64_t corner = dpp_up64(oldS);
 	if (lane == 0) corner = cy.corner;
 	cy.corner = readlane64(oldS, 63);
 	o.across = umax64(key_sub(oldG, SIM_R), key_sub(oldS, SIM_Q + SIM_R));
@@ -328,11 +387,8 @@ __device__ __forceinline__ SweepCell sweep_chunk(uint64_t* S, uint64_t* G, int p
 	const uint64_t c0 = v <= 0 ? sim_key(0, (uint32_t)i, (uint32_t)j) : (uint64_t)((int64_t)corner + (sc << SIM_SHIFT));
 	const uint64_t c1 = umax64(c0, o.across);
 	// gap along the line
-	uint64_t inc = o.valid ? c1 + ((uint64_t)(SIM_R * t) << SIM_SHIFT) : 0;
-	for (int d = 1; d < 64; d <<= 1) { const uint64_t y = shfl_up64n(inc, d); if (lane >= d) inc = umax64(inc, y); }
-	uint64_t exc = shfl_up64(inc);
-	if (lane == 0) exc = 0;
-	exc = umax64(exc, cy.pre);
+	const uint64_t inc = prefix_max64(o.valid ? c1 + ((uint64_t)(SIM_R * t) << SIM_SHIFT) : 0);
+	const uint64_t exc = umax64(dpp_up64(inc), cy.pre);
 	cy.pre = umax64(cy.pre, readlane64(inc, 63));
 	uint64_t g = umax64(key_sub(gapf0, SIM_R * (int64_t)(t + 1)), key_sub(run0, SIM_Q + SIM_R * (int64_t)(t + 1)));
 	if (exc) g = umax64(g, key_sub(exc, SIM_Q + SIM_R * (int64_t)t));
@@ -517,6 +573,8 @@ __global__ void __launch_bounds__(LDS ? 64 : 256) k_sim_resweep(SimResweepArgs a
 	}
 	if (a.debug && lane == 0) {
 		dbg_t[1] = (long long)wall_clock64() - tick; dbg_n[1] = budget1 - budget;
+		atomicAdd((unsigned long long*)a.debug + 6, (unsigned long long)L.dbg_pass); atomicAdd((unsigned long long*)a.debug + 7, (unsigned long long)((long long)L.dbg_bad | ((long long)L.dbg_serial << 32)));
+		atomicAdd((unsigned long long*)a.debug + 8, (unsigned long long)L.dbg_t0); atomicAdd((unsigned long long*)a.debug + 9, (unsigned long long)L.dbg_t1); atomicAdd((unsigned long long*)a.debug + 10, (unsigned long long)L.dbg_t2);
 		for (int k = 0; k < 3; k++) { atomicAdd((unsigned long long*)a.debug + 2 * k, (unsigned long long)dbg_n[k]); atomicAdd((unsigned long long*)a.debug + 2 * k + 1, (unsigned long long)dbg_t[k]); }
 	}
 	nodes_store(L, lane, a.nodes + (int64_t)unit * SIM_K);
@@ -542,13 +600,15 @@ hipError_t launch_sim_forward(const SimFwdArgs& a, int32_t nunit, hipStream_t st
 	return hipGetLastError();
 }
 
-hipError_t launch_sim_resweep(const SimResweepArgs& a, int32_t nunit, hipStream_t st)
+hipError_t launch_sim_resweep(const SimResweepArgs& a, int32_t nunit, bool few_units, hipStream_t st)
 {
 	if (nunit <= 0) return hipSuccess;
 	// the lines' states of one unit: 16 B per target column and per query row; in LDS when that fits one CU's 160 KB (minus a margin)
 	const size_t lds = (size_t)(2 * a.col_stride + 2 * a.row_stride) * sizeof(uint64_t);
 	static const bool want_lds = [] { const char* e = getenv("FASIM_SIM_LDS"); return e ? atoi(e) != 0 : true; }();
-	if (want_lds && lds <= 150 * 1024) {
+	// LDS variant: one unit per CU at a time, each 3-5 x faster -- for the launches in which few units are left (the tail of the
+	// heaviest units); with thousands of units active the 4-units-per-workgroup variant keeps every wave slot of the chip busy
+	if (want_lds && few_units && lds <= 150 * 1024) {
 		static bool attr_set = false;
 		if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_sim_resweep<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
 		hipLaunchKernelGGL(k_sim_resweep<true>, dim3((unsigned)nunit), dim3(64), lds, st, a, nunit);

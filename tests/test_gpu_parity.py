@@ -782,8 +782,9 @@ def _simscan_expected(golden_dir, name, c_length):
 
 
 def test_classic_sim_scan_end_to_end(mod, h19, golden_dir):
-    """-F through fasim_scan (params.classicSim): forward sweep on the GPU, traceback / re-sweeps / triplex records on the host;
-    every record of every unit equals the reference's own SIM() (ref_probe simscan fixtures), demo and planted 12 kb."""
+    """-F through fasim_scan (params.classicSim): forward sweep and the re-sweeps between the K rounds on the GPU (k_sim_forward,
+    k_sim_resweep), traceback / triplex records on the host; every record of every unit equals the reference's own SIM()
+    (ref_probe simscan fixtures), demo and planted 12 kb."""
     e = mod.Engine(0)
     e.set_query(h19)
     p = mod.default_params(classicSim=1, cLength=20)
@@ -795,6 +796,28 @@ def test_classic_sim_scan_end_to_end(mod, h19, golden_dir):
     dna2 = synth.planted_dna(12000, 909, h19, every=700)
     res = e.scan(dna2, p)
     assert res.triplexes() == _simscan_expected(golden_dir, "simF12k.simscan.gz", 20)
+    e.close()
+
+
+def test_classic_sim_resweep_self_check(mod, h19, golden_dir, monkeypatch):
+    """The device re-sweeps of -F (k_sim_resweep, resumable line sweeps + batch node-list replay) against the host restatement
+    of sim.h:884-1141 inside the engine, round by round (FASIM_SIM_RESWEEP=check: node lists and `min` of every unit after
+    every round must be identical, or the scan fails), with a small step budget so that units are suspended and resumed; and
+    host-only re-sweeps give the same records."""
+    dna = synth.planted_dna(12000, 909, h19, every=700)
+    p = mod.default_params(classicSim=1, cLength=20)
+    exp = _simscan_expected(golden_dir, "simF12k.simscan.gz", 20)
+    e = mod.Engine(0)
+    e.set_query(h19)
+    monkeypatch.setenv("FASIM_SIM_RESWEEP", "check")
+    monkeypatch.setenv("FASIM_SIM_BUDGET", "700")
+    assert e.scan(dna, p).triplexes() == exp
+    monkeypatch.delenv("FASIM_SIM_BUDGET")
+    monkeypatch.setenv("FASIM_SIM_RESWEEP", "host")
+    assert e.scan(dna, p).triplexes() == exp
+    monkeypatch.delenv("FASIM_SIM_RESWEEP")
+    res = e.scan(dna, p)
+    assert res.triplexes() == exp and res.stats["kernel_launches"][7] > 1
     e.close()
 
 
