@@ -360,9 +360,22 @@ __device__ __forceinline__ int key_j(uint64_t k) { return (int)(k & 0xffff); }
 
 // 64 cells of a sweep line (sim.h:522-566 and its mirror images): position t0 + lane of n, at index p0 + dir * t.
 // ROW: the line is query row `fix` and positions are target columns; else target column `fix` over query rows.
+// what a chunk reads from memory: the states across the line and the letters of the sequence that varies along it.  The loop
+// over a line loads chunk k + 1 before it computes chunk k, so that the memory latency hides behind the arithmetic.
+struct ChunkIn { uint64_t oldS, oldG; int code; };
+__device__ __forceinline__ ChunkIn chunk_load(const uint64_t* S, const uint64_t* G, int p0, int dir, int t0, int n, const uint8_t* seq, int lane)
+{
+	ChunkIn in;
+	const int t = t0 + lane, p = p0 + dir * t;
+	const bool valid = t < n;
+	in.oldS = valid ? ld_l2(S + p) : 0; in.oldG = valid ? ld_l2(G + p) : 0;
+	in.code = valid ? (int)seq[p - 1] : 250;
+	return in;
+}
+
 template <bool ROW>
-__device__ __forceinline__ SweepCell sweep_chunk(uint64_t* S, uint64_t* G, int p0, int dir, int t0, int n, int fix, uint64_t run0, uint64_t gapf0,
-	SweepCarry& cy, const uint8_t* qcodes, const uint8_t* tcu, int mine, unsigned long long mine_nz, int lane)
+__device__ __forceinline__ SweepCell sweep_chunk(uint64_t* S, uint64_t* G, const ChunkIn& in, int fixcode, int p0, int dir, int t0, int n, int fix,
+	uint64_t run0, uint64_t gapf0, SweepCarry& cy, int mine, unsigned long long mine_nz, int lane)
 {
 	SweepCell o;
 	const int t = t0 + lane;
@@ -370,17 +383,13 @@ __device__ __forceinline__ SweepCell sweep_chunk(uint64_t* S, uint64_t* G, int p
 	const int p = p0 + dir * t;
 	o.pos = p;
 	const int i = ROW ? fix : p, j = ROW ? p : fix;
-	const uint64_t oldS = o.valid ? ld_l2(S + p) : 0, oldG = o.valid ? ld_l2(G + p) : 0;
+	const uint64_t oldS = in.oldS, oldG = in.oldG;
 	uint64_t corner = dpp_up64(oldS);
 	if (lane == 0) corner = cy.corner;
 	cy.corner = readlane64(oldS, 63);
 	o.across = umax64(key_sub(oldG, SIM_R), key_sub(oldS, SIM_Q + SIM_R));
-	int64_t sc = SIM_MISMATCH;
+	const int64_t sc = (in.code == fixcode && fixcode < 4) ? SIM_MATCH : SIM_MISMATCH;
 	bool tk = false;
-	if (o.valid) {
-		const int qc = qcodes[i - 1], tc = tcu[j - 1];
-		if (qc == tc && qc < 4) sc = SIM_MATCH;
-	}
 	// pairs of this line that earlier rounds have aligned (lane e of `mine` = round e's partner of row / column `fix`, 0 = none)
 	for (unsigned long long z = mine_nz; z; z &= z - 1) tk |= __builtin_amdgcn_readlane(mine, (int)__builtin_ctzll(z)) == (ROW ? j : i);
 	const int64_t v = tk ? 0 : sim_score(corner) + sc;
@@ -459,16 +468,21 @@ __global__ void __launch_bounds__(LDS ? 64 : 256) k_sim_resweep(SimResweepArgs a
 	auto outside = [&](uint64_t k) { return key_i(k) > rl && key_j(k) > cl; };
 	// one line; returns the last cell's (c, across, gapf); any_out / positive collected over the line
 	struct LineEnd { uint64_t c, d, g; bool any_out; };
-	auto row_line = [&](int r) {
+	auto row_mine = [&](int r) { return lane < nround ? (int)used[(int64_t)lane * ustride + r] : 0; };
+	auto col_mine = [&](int j) { return lane < nround ? (int)usedc[(int64_t)lane * cstride + j] : 0; };
+	auto row_line = [&](int r, int mine) {
 		LineEnd e; e.any_out = false; e.c = e.d = e.g = 0;
 		const int n = nn - n1 + 1;
 		SweepCarry cy; cy.corner = sim_key(0, (uint32_t)(r + 1), (uint32_t)(nn + 1)); cy.pre = 0;
 		const uint64_t run0 = sim_key(0, (uint32_t)r, (uint32_t)(nn + 1)), gapf0 = sim_key(-SIM_Q, (uint32_t)r, (uint32_t)(nn + 1));
 		bool out = false, pos = false;
-		const int mine = lane < nround ? (int)used[(int64_t)lane * ustride + r] : 0;
+		const int qc = a.qcodes[r - 1];
+		ChunkIn nx = chunk_load(CS, CG, nn, -1, 0, n, tcu, lane);
 		const unsigned long long mine_nz = __ballot(mine != 0);
 		for (int t0 = 0; t0 < n; t0 += 64) {
-			const SweepCell o = sweep_chunk<true>(CS, CG, nn, -1, t0, n, r, run0, gapf0, cy, a.qcodes, tcu, mine, mine_nz, lane);
+			const ChunkIn in = nx;
+			if (t0 + 64 < n) nx = chunk_load(CS, CG, nn, -1, t0 + 64, n, tcu, lane);
+			const SweepCell o = sweep_chunk<true>(CS, CG, in, qc, nn, -1, t0, n, r, run0, gapf0, cy, mine, mine_nz, lane);
 			if (o.valid) { out |= outside(o.c) || outside(o.across) || outside(o.g); pos |= sim_score(o.c) > floor_score; }
 			if (t0 + 64 >= n) { const int l = n - 1 - t0; e.c = readlane64(o.c, l); e.d = readlane64(o.across, l); e.g = readlane64(o.g, l); }
 			budget--;
@@ -479,16 +493,19 @@ __global__ void __launch_bounds__(LDS ? 64 : 256) k_sim_resweep(SimResweepArgs a
 		wave_publish();
 		return e;
 	};
-	auto col_line = [&](int j) {
+	auto col_line = [&](int j, int mine) {
 		LineEnd e; e.any_out = false; e.c = e.d = e.g = 0;
 		const int n = mm - m1 + 1;
 		SweepCarry cy; cy.corner = sim_key(0, (uint32_t)(mm + 1), (uint32_t)(j + 1)); cy.pre = 0;
 		const uint64_t run0 = sim_key(0, (uint32_t)(mm + 1), (uint32_t)j), gapf0 = sim_key(-SIM_Q, (uint32_t)(mm + 1), (uint32_t)j);
 		bool out = false, pos = false;
-		const int mine = lane < nround ? (int)usedc[(int64_t)lane * cstride + j] : 0;
+		const int tc = tcu[j - 1];
+		ChunkIn nx = chunk_load(RS, RG, mm, -1, 0, n, a.qcodes, lane);
 		const unsigned long long mine_nz = __ballot(mine != 0);
 		for (int t0 = 0; t0 < n; t0 += 64) {
-			const SweepCell o = sweep_chunk<false>(RS, RG, mm, -1, t0, n, j, run0, gapf0, cy, a.qcodes, tcu, mine, mine_nz, lane);
+			const ChunkIn in = nx;
+			if (t0 + 64 < n) nx = chunk_load(RS, RG, mm, -1, t0 + 64, n, a.qcodes, lane);
+			const SweepCell o = sweep_chunk<false>(RS, RG, in, tc, mm, -1, t0, n, j, run0, gapf0, cy, mine, mine_nz, lane);
 			if (o.valid) { out |= outside(o.c) || outside(o.across) || outside(o.g); pos |= sim_score(o.c) > floor_score; }
 			if (t0 + 64 >= n) { const int l = n - 1 - t0; e.c = readlane64(o.c, l); e.d = readlane64(o.across, l); e.g = readlane64(o.g, l); }
 			budget--;
@@ -504,21 +521,23 @@ __global__ void __launch_bounds__(LDS ? 64 : 256) k_sim_resweep(SimResweepArgs a
 	long long tick = a.debug ? (long long)wall_clock64() : 0;
 	// ---- phase 0: backwards over the node's rectangle
 	if (phase == 0) {
-		while (i >= m1 && budget > 0) { row_line(i); i--; }
+		int mn = row_mine(i);                                   // (the next line's list is fetched while this line is swept)
+		while (i >= m1 && budget > 0) { const int cur = mn; mn = row_mine(i - 1); row_line(i, cur); i--; }
 		if (i < m1) { phase = 1; rl = m1; cl = n1; grow_rows = grow_cols = true; }
 	}
 	// ---- phase 1: growth (sim.h:933-1084): rl / cl = the smallest start row / column a state may have without leaving
 	while (phase == 1 && budget > 0) {
 		if ((grow_rows && m1 > 1) || (grow_cols && n1 > 1)) {
+			const int mr = m1 > 1 ? row_mine(m1 - 1) : 0, mc = n1 > 1 ? col_mine(n1 - 1) : 0;
 			if (grow_rows && m1 > 1) {
 				m1--;
-				const LineEnd e = row_line(m1);
+				const LineEnd e = row_line(m1, mr);
 				grow_rows = e.any_out;
 				if (!grow_cols && (outside(e.c) || outside(e.d) || outside(e.g))) grow_cols = true;
 			}
 			if (grow_cols && n1 > 1) {
 				n1--;
-				const LineEnd e = col_line(n1);
+				const LineEnd e = col_line(n1, mc);
 				grow_cols = e.any_out;
 				if (!grow_rows && (outside(e.c) || outside(e.d) || outside(e.g))) grow_rows = true;
 			}
@@ -552,13 +571,19 @@ __global__ void __launch_bounds__(LDS ? 64 : 256) k_sim_resweep(SimResweepArgs a
 	// ---- phase 2: forwards over the final rectangle, new nodes in row-major order (sim.h:1086-1141)
 	if (phase == 2) {
 		const int n = nn - n1;
+		int mn = row_mine(min(i, M + 1));
 		for (; i <= mm && budget > 0; i++) {
 			SweepCarry cy; cy.corner = sim_key(0, (uint32_t)(i - 1), (uint32_t)n1); cy.pre = 0;
 			const uint64_t run0 = sim_key(0, (uint32_t)i, (uint32_t)n1), gapf0 = sim_key(-SIM_Q, (uint32_t)i, (uint32_t)n1);
-			const int mine = lane < nround ? (int)used[(int64_t)lane * ustride + i] : 0;
+			const int mine = mn;
+			mn = row_mine(i + 1);
 			const unsigned long long mine_nz = __ballot(mine != 0);
+			const int qc = a.qcodes[i - 1];
+			ChunkIn nx = chunk_load(CS, CG, n1 + 1, 1, 0, n, tcu, lane);
 			for (int t0 = 0; t0 < n; t0 += 64) {
-				const SweepCell o = sweep_chunk<true>(CS, CG, n1 + 1, 1, t0, n, i, run0, gapf0, cy, a.qcodes, tcu, mine, mine_nz, lane);
+				const ChunkIn in = nx;
+				if (t0 + 64 < n) nx = chunk_load(CS, CG, n1 + 1, 1, t0 + 64, n, tcu, lane);
+				const SweepCell o = sweep_chunk<true>(CS, CG, in, qc, n1 + 1, 1, t0, n, i, run0, gapf0, cy, mine, mine_nz, lane);
 				budget--;
 				unsigned long long ev = __ballot(o.valid && sim_score(o.c) > floor_score);
 				if (ev) floor_score = 1;                         // min = addnode() (sim.h:1131): 1 from the first new cell on

@@ -122,15 +122,17 @@ int fasim_align_batch(fasim_engine* e, const char* windows, const int64_t* offse
  * execution order of LongTarget(): target[n] and src[n] (src is NUL-padded if letters were dropped). */
 int fasim_encode_unit(const char* seg, int32_t n, int32_t enc, char* target, char* src);
 
-/* ---- row f3 (first step): the -F path, classic SIM (sim.h:410-1143) ----------------------------- */
+/* ---- row f3: the -F path, classic SIM (sim.h:410-1143) ------------------------------------------- */
 /* The forward sweep of SIM() (sim.h:506-571) on the GPU: local alignment scores with start points over the whole
  * (query x target) matrix, every cell above `min_score` fed to the K = 50 node list in row-major order (addnode,
  * sim.h:99-148).  Returns the node list the sweep leaves, in list order: what the reference holds when its traceback
  * loop starts (sim.h:572).  Scores are the reference's x10 values; min_score is compared unscaled, as the reference
- * does (sim.h:567).  fasim_scan with params.classicSim = 1 runs the whole -F path: this sweep on the GPU, then the
- * linear-space traceback, the region re-sweeps and the triplex records on host threads (csrc/host_sim.cpp).
+ * does (sim.h:567).  fasim_scan with params.classicSim = 1 runs the whole -F path: this sweep on the GPU, then K rounds in
+ * lock step over the units of a batch -- best node, linear-space traceback and triplex record on host threads
+ * (csrc/host_sim.cpp), the backward / growing / forward re-sweeps of the influenced rectangles (sim.h:884-1141) on the GPU
+ * (k_sim_resweep, csrc/sim.hip).
  * Query and targets: ACGT (other letters score as mismatches; the reference reads an uninitialised table there), at most
- * 65535 long (16-bit start fields in the 64-bit DP keys). */
+ * 65534 long (16-bit start fields in the 64-bit DP keys; a re-sweep starts lines at row M + 1 / column N + 1). */
 typedef struct fasim_sim_node { int64_t score, stari, starj, endi, endj, top, bot, left, right; } fasim_sim_node;
 #define FASIM_SIM_K 50
 typedef struct fasim_result fasim_result;      /* defined below */
