@@ -97,8 +97,8 @@ struct SimResweepArgs {
 	const uint8_t* qcodes; int32_t m;
 	const SimRoundReq* req;         // [unit]
 	const uint32_t* pairs;          // (query row << 16) | target column, 1-based, of all units' requests
-	uint16_t* usedc;                // [unit][SIM_K][col_stride]: the same per target column (the query row aligned to it)
-	uint16_t* used; int32_t* used_cnt;   // [unit][SIM_K][m + 2]: per round the target column aligned to the query row (0 = none); [unit]: rounds swept so far
+	uint16_t* usedc;                // [unit][col_stride][SIM_K]: the same per target column (the query row aligned to it)
+	uint16_t* used; int32_t* used_cnt;   // [unit][m + 2][SIM_K]: per query row and round the target column aligned to it (0 = none); [unit]: rounds swept so far
 	uint64_t* colS; uint64_t* colG; // [unit][col_stride]: per target column the DP state across the sweep line (CC/RR/EE and DD/SS/FF of sim.h as one key each)
 	uint64_t* rowS; uint64_t* rowG; // [unit][row_stride]: per query row (HH/II/JJ and WW/XX/YY)
 	int64_t col_stride, row_stride;
@@ -107,7 +107,7 @@ struct SimResweepArgs {
 	int32_t* pending;               // [unit]: 1 = out of budget, to be continued
 	SimSweepState* state;           // [unit]
 	int32_t budget;                 // 64-cell steps per unit and launch
-	uint64_t* debug;                // FASIM_SIM_DEBUG=1: 3 x (count, 100 MHz ticks) summed over the units: backward steps, forward steps, events
+	uint64_t* debug;                // FASIM_SIM_DEBUG=1: 3 x (count, 100 MHz ticks) summed over the units: backward steps, forward steps, events; replay passes, outranking events
 };
 
 // packed 4-bit score table: entry q (0..5) of row t = score(t,q)+BIAS

@@ -22,6 +22,7 @@ int sim_forward_units(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, c
 	if (E->m > 65534 || maxlen > 65534) return fail(E, FASIM_E_UNSUPPORTED, "the SIM forward sweep holds start points in 16 bits: query %d / target %d nt is too long", E->m, maxlen);
 	const int64_t row_stride = (maxlen + 2 + 15) & ~15;
 	const uint32_t cap = (uint32_t)((maxlen + 15) & ~15);
+	ProfScope fwd_wall(13, "-F forward sweep (k_sim_forward slices), wall");
 	DevBuf& d_min = E->sim_min; DevBuf& d_row = E->sim_row; DevBuf& d_ev = E->sim_ev; DevBuf& d_cnt = E->sim_cnt; DevBuf& d_nodes = E->sim_nodes;
 	int rc = upload(E, d_min, min_scores, sizeof(int64_t) * nrun); if (rc) return rc;
 	// Units per launch = waves in flight.  The node-list replay is a serial chain per wave, so the chip wants all of its 8192 wave
@@ -100,7 +101,15 @@ int sim_resweep_rounds(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, 
 	const size_t used_per_unit = (size_t)SIM_K * (size_t)(M + 2) * sizeof(uint16_t);
 	const size_t usedc_per_unit = (size_t)SIM_K * (size_t)col_stride * sizeof(uint16_t);
 	const size_t per_unit = used_per_unit + usedc_per_unit + (size_t)(2 * col_stride + 2 * row_stride) * sizeof(uint64_t);
-	const int slice = (int)std::max<size_t>(1, std::min<size_t>((size_t)cnt, ((size_t)4 << 30) / per_unit));
+	// units advancing together: as many as a quarter of the free HBM holds state for (0.9 MB per unit for H19 x 5 kb) -- every
+	// slice has its own tail of heavy units, so fewer slices are better
+	size_t state_budget = (size_t)4 << 30;
+	{
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+			state_budget = std::max(state_budget, (E->sim_used.cap + E->sim_usedc.cap + E->sim_col.cap + E->sim_rowst.cap + free_b) / 4);
+	}
+	const int slice = (int)std::max<size_t>(1, std::min<size_t>((size_t)cnt, state_budget / per_unit));
 	std::vector<SimRoundReq> req((size_t)slice);
 	std::vector<uint32_t> pairs;
 	std::vector<std::vector<std::pair<int, int>>> np((size_t)slice);
@@ -121,6 +130,7 @@ int sim_resweep_rounds(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, 
 	static const bool debug = getenv("FASIM_SIM_DEBUG") != nullptr;
 	long launches = 0, unit_launches = 0;
 	if (debug) { HIPOK(E->sim_debug.ensure(128)); HIPOK(hipMemsetAsync(E->sim_debug.p, 0, 128, E->st)); }
+	ProfScope rounds_wall(31, "-F rounds (re-sweep launches + host half), wall");
 	for (int s0 = 0; s0 < cnt; s0 += slice) {
 		const int n = std::min(slice, cnt - s0);
 		HIPOK(E->sim_used.ensure(used_per_unit * n)); HIPOK(E->sim_rounds.ensure(sizeof(int32_t) * n));
@@ -175,6 +185,7 @@ int sim_resweep_rounds(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, 
 			a.col_stride = col_stride; a.row_stride = row_stride;
 			a.nodes = E->sim_nodes.as<SimNodeDev>(); a.node_count = E->sim_cnt.as<int32_t>(); a.floor_out = E->sim_floor.as<int32_t>();
 			a.pending = E->sim_pending.as<int32_t>(); a.state = E->sim_state.as<SimSweepState>(); a.budget = budget_env ? budget_env : (active > 1024 ? 16384 : 65536); a.debug = debug ? E->sim_debug.as<uint64_t>() : nullptr;
+			const double tl0 = now_s();
 			hipError_t he;
 			{ TimedScope ts(E, 7); he = launch_sim_resweep(a, n, active <= 512, E->st); }
 			if (he != hipSuccess) return fail(E, FASIM_E_HIP, "sim_resweep launch failed: %s", hipGetErrorString(he));
@@ -185,6 +196,7 @@ int sim_resweep_rounds(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, 
 			HIPOK(hipStreamSynchronize(E->st));
 			for (int k = 0; k < n; k++) if (req[(size_t)k].active && (hc[(size_t)k] < 0 || hc[(size_t)k] > FASIM_SIM_K)) return fail(E, FASIM_E_HIP, "sim_resweep: bad node count");
 			for (int k = 0; k < n; k++) pend[(size_t)k] = req[(size_t)k].active && hp[(size_t)k] != 0;
+			if (debug) { int np_ = 0; for (int k = 0; k < n; k++) np_ += pend[(size_t)k]; fprintf(stderr, "[fasim sim] launch %ld: %d active, %d suspended, budget %d, %.1f ms\n", launches, active, np_, a.budget, 1e3 * (now_s() - tl0)); }
 			if (mode == 2) {
 				std::atomic<int> bad(-1);
 				parallel_units(n, nthreads, [&](int k) {
@@ -206,10 +218,10 @@ int sim_resweep_rounds(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, 
 		}
 	}
 	if (debug) {
-		uint64_t d[11];
+		uint64_t d[8];
 		HIPOK(hipMemcpy(d, E->sim_debug.p, sizeof d, hipMemcpyDeviceToHost));
-		fprintf(stderr, "[fasim sim] %d units, %ld launches (%ld unit-launches); backward %llu steps %.3f s, forward %llu steps %.3f s of which %llu events %.3f s (wave-seconds); replay passes %llu, outranking events %llu, solid hits %llu; hit loop %.3f s, junk run %.3f s, solid updates %.3f s\n",
-			cnt, launches, unit_launches, (unsigned long long)d[0], 1e-8 * (double)d[1], (unsigned long long)d[2], 1e-8 * (double)d[3], (unsigned long long)d[4], 1e-8 * (double)d[5], (unsigned long long)d[6], (unsigned long long)(d[7] & 0xffffffffu), (unsigned long long)(d[7] >> 32), 1e-8 * (double)d[8], 1e-8 * (double)d[9], 1e-8 * (double)d[10]);
+		fprintf(stderr, "[fasim sim] %d units, %ld launches (%ld unit-launches); backward %llu steps %.3f s, forward %llu steps %.3f s of which %llu events %.3f s (wave-seconds); replay passes %llu, outranking events %llu\n",
+			cnt, launches, unit_launches, (unsigned long long)d[0], 1e-8 * (double)d[1], (unsigned long long)d[2], 1e-8 * (double)d[3], (unsigned long long)d[4], 1e-8 * (double)d[5], (unsigned long long)d[6], (unsigned long long)d[7]);
 	}
 	return FASIM_OK;
 }
@@ -543,6 +555,14 @@ int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rna_lens,
 			const int64_t rounds = std::max<int64_t>(1, (seg_count + target * (int64_t)nworkers - 1) / (target * (int64_t)nworkers));
 			seg_batch = std::max<int64_t>(1, std::min<int64_t>((seg_count + rounds * nworkers - 1) / (rounds * nworkers), ((int64_t)8 << 30) / ((int64_t)4 * nenc * tstride)));
 			if (E->opt_taper < 0) taper_pct = 25;
+		}
+		if (p.classicSim && !envb && E->opt_seg_batch <= 0) {
+			// -F: a batch's rounds advance launch by launch and end with the tail of its heaviest unit, so several
+			// batches should be in flight -- but each batch's host half runs on its worker's share of the cores, so not too many
+			// either: about eight batches per record, 16 ... 128 segments (768 ... 6 144 units) each.  Measured (profiles/r03_simF_500kb.txt):
+			// 500 kb 36 s as one batch, 25.6 s as four to seven; 2 Mb 49.8 s as eight batches of 52 segments, 97 s as twenty of 21.
+			seg_batch = std::max<int64_t>(16, std::min<int64_t>(128, (seg_count + 7) / 8));
+			taper_pct = 0;
 		}
 		std::vector<std::pair<int64_t, int64_t>> chunks;
 		{

@@ -89,8 +89,7 @@ struct NodeList {
 	int cnt;                                                  // wave-uniform
 	int low; unsigned long long low_mask;                     // valid while cnt == SIM_K (nodes_add keeps them exact)
 	int junk, l2;                                             // batch path: the first node of lowest score; a lower bound of all other scores
-	int dbg_pass, dbg_bad, dbg_serial;                        // FASIM_SIM_DEBUG counters
-	long long dbg_t0, dbg_t1, dbg_t2;
+	int dbg_pass, dbg_bad;                                    // FASIM_SIM_DEBUG counters
 };
 __device__ __forceinline__ void nodes_find_low(NodeList& L, int lane)
 {
@@ -148,14 +147,12 @@ __device__ __forceinline__ void nodes_add_batch(NodeList& L, int lane, bool has,
 			// list not full yet: one event at a time
 			const int b = (int)__builtin_ctzll(todo);
 			todo &= todo - 1;
-			L.dbg_serial++;
 			nodes_add(L, lane, __builtin_amdgcn_readlane(c, b), __builtin_amdgcn_readlane(start, b), ei, __builtin_amdgcn_readlane(ej, b));
 			if (L.cnt == SIM_K) nodes_steady(L, lane);
 			continue;
 		}
 		const int t = L.junk;
 		L.dbg_pass++;
-		const long long tq0 = (long long)wall_clock64();
 		const bool mine = (todo >> lane) & 1;
 		int hit = -1;
 		{
@@ -171,7 +168,6 @@ __device__ __forceinline__ void nodes_add_batch(NodeList& L, int lane, bool has,
 		const bool now = (part >> lane) & 1;
 		const bool junk = now && hit < 0;
 		const unsigned long long jm = __ballot(junk);
-		const long long tq1 = (long long)wall_clock64();
 		if (jm) {
 			const int z = 63 - (int)__builtin_clzll(jm);                       // the last junk event and the run of its start point
 			const int sz = __builtin_amdgcn_readlane(start, z);
@@ -189,8 +185,6 @@ __device__ __forceinline__ void nodes_add_batch(NodeList& L, int lane, bool has,
 				}
 			}
 		}
-		const long long tq2 = (long long)wall_clock64();
-		L.dbg_t0 += tq1 - tq0; L.dbg_t1 += tq2 - tq1; L.dbg_serial += __builtin_popcountll(__ballot(now && hit >= 0));
 		for (unsigned long long hm = __ballot(now && hit >= 0); hm;) {
 			const int k = __builtin_amdgcn_readlane(hit, (int)__builtin_ctzll(hm));
 			const unsigned long long mk = __ballot(now && hit == k);
@@ -204,7 +198,6 @@ __device__ __forceinline__ void nodes_add_batch(NodeList& L, int lane, bool has,
 				L.top = min(L.top, ei); L.bot = max(L.bot, ei); L.left = min(L.left, first_j); L.right = max(L.right, last_j);
 			}
 		}
-		L.dbg_t2 += (long long)wall_clock64() - tq2;
 		todo &= ~part;
 		if (bad) {
 			const int b = (int)__builtin_ctzll(bad);
@@ -218,7 +211,7 @@ __device__ __forceinline__ void nodes_add_batch(NodeList& L, int lane, bool has,
 }
 __device__ __forceinline__ void nodes_load(NodeList& L, int lane, const SimNodeDev* src, int cnt)
 {
-	L.cnt = cnt; L.low = 0; L.low_mask = 0; L.junk = -1; L.l2 = 0; L.dbg_pass = L.dbg_bad = L.dbg_serial = 0; L.dbg_t0 = L.dbg_t1 = L.dbg_t2 = 0;
+	L.cnt = cnt; L.low = 0; L.low_mask = 0; L.junk = -1; L.l2 = 0; L.dbg_pass = L.dbg_bad = 0;
 	L.score = L.start = L.endi = L.endj = L.top = L.bot = L.left = L.right = 0;
 	if (lane < cnt) {
 		const SimNodeDev nd = src[lane];
@@ -423,8 +416,8 @@ __global__ void __launch_bounds__(LDS ? 64 : 256) k_sim_resweep(SimResweepArgs a
 	const int M = a.m;
 	const int ustride = M + 2, cstride = (int)a.col_stride;
 	const uint8_t* tcu = a.tcodes + (int64_t)unit * a.tstride;
-	uint16_t* used = a.used + (int64_t)unit * SIM_K * ustride;          // [round][query row] -> target column
-	uint16_t* usedc = a.usedc + (int64_t)unit * SIM_K * cstride;        // [round][target column] -> query row
+	uint16_t* used = a.used + (int64_t)unit * SIM_K * ustride;          // [query row][round] -> target column (a line's 50 entries share a cache line or two:
+	uint16_t* usedc = a.usedc + (int64_t)unit * SIM_K * cstride;        // [target column][round] -> query row   [round][line] cost 49 line fetches per sweep line)
 	// the lines' states: in LDS when (columns + rows) fit (an LDS access is ~100 cycles, an L2 round trip ~2 us), with a home
 	// in HBM that only an unfinished unit uses, between two launches
 	uint64_t* gCS = a.colS + (int64_t)unit * a.col_stride; uint64_t* gCG = a.colG + (int64_t)unit * a.col_stride;
@@ -442,8 +435,8 @@ __global__ void __launch_bounds__(LDS ? 64 : 256) k_sim_resweep(SimResweepArgs a
 		const int round = a.used_cnt[unit];
 		for (int k = lane; k < rq.pairs_count; k += 64) {
 			const uint32_t pr = a.pairs[rq.pairs_first + k];
-			used[(int64_t)round * ustride + (pr >> 16)] = (uint16_t)(pr & 0xffff);
-			usedc[(int64_t)round * cstride + (pr & 0xffff)] = (uint16_t)(pr >> 16);
+			used[(int64_t)(pr >> 16) * SIM_K + round] = (uint16_t)(pr & 0xffff);
+			usedc[(int64_t)(pr & 0xffff) * SIM_K + round] = (uint16_t)(pr >> 16);
 		}
 		nround = round + 1;
 		phase = 0; i = mm; m1 = rq.m1; n1 = rq.n1; rl = cl = 0; floor_score = rq.floor_score;
@@ -468,8 +461,8 @@ __global__ void __launch_bounds__(LDS ? 64 : 256) k_sim_resweep(SimResweepArgs a
 	auto outside = [&](uint64_t k) { return key_i(k) > rl && key_j(k) > cl; };
 	// one line; returns the last cell's (c, across, gapf); any_out / positive collected over the line
 	struct LineEnd { uint64_t c, d, g; bool any_out; };
-	auto row_mine = [&](int r) { return lane < nround ? (int)used[(int64_t)lane * ustride + r] : 0; };
-	auto col_mine = [&](int j) { return lane < nround ? (int)usedc[(int64_t)lane * cstride + j] : 0; };
+	auto row_mine = [&](int r) { return lane < nround ? (int)used[(int64_t)r * SIM_K + lane] : 0; };
+	auto col_mine = [&](int j) { return lane < nround ? (int)usedc[(int64_t)j * SIM_K + lane] : 0; };
 	auto row_line = [&](int r, int mine) {
 		LineEnd e; e.any_out = false; e.c = e.d = e.g = 0;
 		const int n = nn - n1 + 1;
@@ -598,8 +591,7 @@ __global__ void __launch_bounds__(LDS ? 64 : 256) k_sim_resweep(SimResweepArgs a
 	}
 	if (a.debug && lane == 0) {
 		dbg_t[1] = (long long)wall_clock64() - tick; dbg_n[1] = budget1 - budget;
-		atomicAdd((unsigned long long*)a.debug + 6, (unsigned long long)L.dbg_pass); atomicAdd((unsigned long long*)a.debug + 7, (unsigned long long)((long long)L.dbg_bad | ((long long)L.dbg_serial << 32)));
-		atomicAdd((unsigned long long*)a.debug + 8, (unsigned long long)L.dbg_t0); atomicAdd((unsigned long long*)a.debug + 9, (unsigned long long)L.dbg_t1); atomicAdd((unsigned long long*)a.debug + 10, (unsigned long long)L.dbg_t2);
+		atomicAdd((unsigned long long*)a.debug + 6, (unsigned long long)L.dbg_pass); atomicAdd((unsigned long long*)a.debug + 7, (unsigned long long)L.dbg_bad);
 		for (int k = 0; k < 3; k++) { atomicAdd((unsigned long long*)a.debug + 2 * k, (unsigned long long)dbg_n[k]); atomicAdd((unsigned long long*)a.debug + 2 * k + 1, (unsigned long long)dbg_t[k]); }
 	}
 	nodes_store(L, lane, a.nodes + (int64_t)unit * SIM_K);

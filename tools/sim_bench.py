@@ -5,6 +5,8 @@ import __graft_entry__ as entry, synth
 mod = entry.load(); eng = mod.Engine(0)
 _, rna = synth.read_fasta("tests/golden/H19.fa"); eng.set_query(rna)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
+if len(sys.argv) > 2:
+    eng.set_option("seg_batch", int(sys.argv[2]))      # segments per batch: several batches in flight on the worker engines
 dna = mod.synth_dna(n, 4242)
 p = mod.default_params(); p.classicSim = 1
 t0 = time.perf_counter(); r = eng.scan(dna, p); dt = time.perf_counter() - t0
