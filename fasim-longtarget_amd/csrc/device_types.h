@@ -95,6 +95,7 @@ struct SimSweepState { int32_t phase, i, m1, n1, rl, cl, floor_score, nround, gr
 struct SimResweepArgs {
 	const uint8_t* tcodes; const int32_t* unit_len; int32_t tstride;
 	const uint8_t* qcodes; int32_t m;
+	const int32_t* active_idx;      // [launched slots]: the units this launch works on
 	const SimRoundReq* req;         // [unit]
 	const uint32_t* pairs;          // (query row << 16) | target column, 1-based, of all units' requests
 	uint16_t* usedc;                // [unit][col_stride][SIM_K]: the same per target column (the query row aligned to it)
@@ -106,7 +107,8 @@ struct SimResweepArgs {
 	int32_t* floor_out;             // [unit]: the reference's `min` after the round (0, then 1)
 	int32_t* pending;               // [unit]: 1 = out of budget, to be continued
 	SimSweepState* state;           // [unit]
-	int32_t budget;                 // 64-cell steps per unit and launch
+	int32_t budget;                 // at most this many 64-cell steps per unit and launch ...
+	int64_t slice_ticks;            // ... and this much time (100 MHz ticks): what normally ends a unit's share of a launch
 	uint64_t* debug;                // FASIM_SIM_DEBUG=1: 3 x (count, 100 MHz ticks) summed over the units: backward steps, forward steps, events; replay passes, outranking events
 };
 

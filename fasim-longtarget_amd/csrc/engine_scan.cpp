@@ -112,6 +112,7 @@ int sim_resweep_rounds(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, 
 	const int slice = (int)std::max<size_t>(1, std::min<size_t>((size_t)cnt, state_budget / per_unit));
 	std::vector<SimRoundReq> req((size_t)slice);
 	std::vector<uint32_t> pairs;
+	std::vector<int32_t> act;
 	std::vector<std::vector<std::pair<int, int>>> np((size_t)slice);
 	// node lists both ways every launch (3.6 KB per unit): pinned, or the copies are staged at a few GB/s
 	const size_t hn_bytes = sizeof(fasim_sim_node) * (size_t)slice * FASIM_SIM_K;
@@ -123,8 +124,10 @@ int sim_resweep_rounds(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, 
 	fasim_sim_node* const hn = (fasim_sim_node*)E->pin_sim;
 	std::vector<int32_t> hc((size_t)slice), hf((size_t)slice), hp((size_t)slice);
 	std::vector<char> pend((size_t)slice);
-	// 64-cell steps per unit and launch: a unit that needs more (a re-sweep of most of the matrix) carries on in the next launch.
-	// The average round of H19 x 5 kb takes 10 k steps, the heaviest unit of a 500 kb record 12 M steps in all.
+	// A unit's share of a launch: a time slice (50 ms while more than 1 024 units are active, 150 ms for the tail; the kernel reads
+	// the clock every eighth line), or a number of 64-cell steps when FASIM_SIM_BUDGET is set (tests).  A unit that needs more (a
+	// re-sweep of most of the matrix) carries on in the next launch: the average round of H19 x 5 kb takes 10 k steps, the heaviest
+	// unit of a 500 kb record 12 M steps in all.
 	const char* budget_s = getenv("FASIM_SIM_BUDGET");       // (tests: a small budget exercises suspend / resume)
 	const int budget_env = budget_s && atoi(budget_s) > 0 ? atoi(budget_s) : 0;
 	static const bool debug = getenv("FASIM_SIM_DEBUG") != nullptr;
@@ -156,12 +159,12 @@ int sim_resweep_rounds(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, 
 				req[(size_t)k] = r;
 			});
 			g_prof.add(30, "-F rounds: host half (best node, traceback, record), wall", now_s() - t0);
-			pairs.clear();
+			pairs.clear(); act.clear();
 			int active = 0;
 			for (int k = 0; k < n; k++) {
 				SimRoundReq& r = req[(size_t)k];
 				if (!r.active) { hc[(size_t)k] = 0; continue; }
-				active++;
+				active++; act.push_back(k);
 				if (r.active == 2) continue;                    // its node list is the one the last launch left
 				r.pairs_first = (int32_t)pairs.size(); r.pairs_count = (int32_t)np[(size_t)k].size();
 				for (const auto& pr : np[(size_t)k]) pairs.push_back(((uint32_t)pr.first << 16) | (uint32_t)pr.second);
@@ -173,21 +176,22 @@ int sim_resweep_rounds(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, 
 			launches++; unit_launches += active;
 			int rc = upload_async(E, E->sim_req, req.data(), sizeof(SimRoundReq) * n); if (rc) return rc;
 			rc = upload_async(E, E->sim_pairs, pairs.data(), sizeof(uint32_t) * pairs.size()); if (rc) return rc;
+			rc = upload_async(E, E->sim_active, act.data(), sizeof(int32_t) * act.size()); if (rc) return rc;
 			HIPOK(hipMemcpyAsync(E->sim_cnt.p, hc.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, E->st));
 			HIPOK(hipMemcpyAsync(E->sim_nodes.p, hn, sizeof(fasim_sim_node) * (size_t)n * FASIM_SIM_K, hipMemcpyHostToDevice, E->st));
 			SimResweepArgs a;
 			a.tcodes = tcodes_dev + (size_t)(first + s0) * tstride; a.unit_len = unit_len_dev + first + s0; a.tstride = tstride;
 			a.qcodes = E->qsim.as<uint8_t>(); a.m = M;
-			a.req = E->sim_req.as<SimRoundReq>(); a.pairs = E->sim_pairs.as<uint32_t>();
+			a.active_idx = E->sim_active.as<int32_t>(); a.req = E->sim_req.as<SimRoundReq>(); a.pairs = E->sim_pairs.as<uint32_t>();
 			a.used = E->sim_used.as<uint16_t>(); a.usedc = E->sim_usedc.as<uint16_t>(); a.used_cnt = E->sim_rounds.as<int32_t>();
 			a.colS = E->sim_col.as<uint64_t>(); a.colG = a.colS + (size_t)n * col_stride;
 			a.rowS = E->sim_rowst.as<uint64_t>(); a.rowG = a.rowS + (size_t)n * row_stride;
 			a.col_stride = col_stride; a.row_stride = row_stride;
 			a.nodes = E->sim_nodes.as<SimNodeDev>(); a.node_count = E->sim_cnt.as<int32_t>(); a.floor_out = E->sim_floor.as<int32_t>();
-			a.pending = E->sim_pending.as<int32_t>(); a.state = E->sim_state.as<SimSweepState>(); a.budget = budget_env ? budget_env : (active > 1024 ? 16384 : 65536); a.debug = debug ? E->sim_debug.as<uint64_t>() : nullptr;
+			a.pending = E->sim_pending.as<int32_t>(); a.state = E->sim_state.as<SimSweepState>(); a.budget = budget_env ? budget_env : (1 << 20); a.slice_ticks = budget_env ? ((int64_t)1 << 40) : (active > 1024 ? 5000000 : 15000000); a.debug = debug ? E->sim_debug.as<uint64_t>() : nullptr;
 			const double tl0 = now_s();
 			hipError_t he;
-			{ TimedScope ts(E, 7); he = launch_sim_resweep(a, n, active <= 512, E->st); }
+			{ TimedScope ts(E, 7); he = launch_sim_resweep(a, active, active <= 256 /* one unit per CU: all at once */, E->st); }
 			if (he != hipSuccess) return fail(E, FASIM_E_HIP, "sim_resweep launch failed: %s", hipGetErrorString(he));
 			HIPOK(hipMemcpyAsync(hc.data(), E->sim_cnt.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, E->st));
 			HIPOK(hipMemcpyAsync(hf.data(), E->sim_floor.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, E->st));
@@ -559,8 +563,9 @@ int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rna_lens,
 		if (p.classicSim && !envb && E->opt_seg_batch <= 0) {
 			// -F: a batch's rounds advance launch by launch and end with the tail of its heaviest unit, so several
 			// batches should be in flight -- but each batch's host half runs on its worker's share of the cores, so not too many
-			// either: about eight batches per record, 16 ... 128 segments (768 ... 6 144 units) each.  Measured (profiles/r03_simF_500kb.txt):
-			// 500 kb 36 s as one batch, 25.6 s as four to seven; 2 Mb 49.8 s as eight batches of 52 segments, 97 s as twenty of 21.
+			// either: about eight batches per record, 16 ... 128 segments (768 ... 6 144 units) each.  Measured with step-count launches
+			// (profiles/r03_simF_500kb.txt): 500 kb 36 s as one batch, 25.6 s as four to seven; 2 Mb 49.8 s as eight batches of 52
+			// segments, 97 s as twenty of 21 (the final time-sliced build: 18.2 / 17.8 s and 27.1 s).
 			seg_batch = std::max<int64_t>(16, std::min<int64_t>(128, (seg_count + 7) / 8));
 			taper_pct = 0;
 		}

@@ -408,8 +408,11 @@ template <bool LDS>
 __global__ void __launch_bounds__(LDS ? 64 : 256) k_sim_resweep(SimResweepArgs a, int32_t nunit)
 {
 	extern __shared__ uint64_t sim_lds[];
-	const int unit = LDS ? (int)blockIdx.x : (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
-	if (unit >= nunit) return;
+	// the launch covers the ACTIVE units only, through an index list: consecutive workgroups go to consecutive XCDs, and the heavy
+	// units of a batch tend to be the same few of the 48 encodings (unit = segment x 48 + encoding), i.e. the same XCDs
+	const int slot = LDS ? (int)blockIdx.x : (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
+	if (slot >= nunit) return;
+	const int unit = a.active_idx[slot];
 	const int lane = threadIdx.x & 63;
 	const SimRoundReq rq = a.req[unit];
 	if (!rq.active) return;
@@ -456,6 +459,11 @@ __global__ void __launch_bounds__(LDS ? 64 : 256) k_sim_resweep(SimResweepArgs a
 		}
 	}
 	int budget = a.budget;
+	// the time slice of a launch: checked every eighth line, so that a unit with cheap steps is not held to the pace of the one with
+	// the most expensive steps (per launch every unit gets the same time, not the same number of steps)
+	const long long t_start = (long long)wall_clock64();
+	int lines = 0, steps = 0;
+	auto slice_over = [&]() { if ((++lines & 7) == 0 && (long long)wall_clock64() - t_start > a.slice_ticks) budget = 0; };
 	long long dbg_t[3] = { 0, 0, 0 }, dbg_n[3] = { 0, 0, 0 };      // a.debug: 100 MHz ticks / counts of backward steps, forward steps, events
 
 	auto outside = [&](uint64_t k) { return key_i(k) > rl && key_j(k) > cl; };
@@ -478,12 +486,13 @@ __global__ void __launch_bounds__(LDS ? 64 : 256) k_sim_resweep(SimResweepArgs a
 			const SweepCell o = sweep_chunk<true>(CS, CG, in, qc, nn, -1, t0, n, r, run0, gapf0, cy, mine, mine_nz, lane);
 			if (o.valid) { out |= outside(o.c) || outside(o.across) || outside(o.g); pos |= sim_score(o.c) > floor_score; }
 			if (t0 + 64 >= n) { const int l = n - 1 - t0; e.c = readlane64(o.c, l); e.d = readlane64(o.across, l); e.g = readlane64(o.g, l); }
-			budget--;
+			budget--; steps++;
 		}
 		e.any_out = __ballot(out) != 0;
 		if (__ballot(pos)) positive = true;
 		if (lane == 0) { RS[r] = e.c; RG[r] = e.g; }
 		wave_publish();
+		slice_over();
 		return e;
 	};
 	auto col_line = [&](int j, int mine) {
@@ -501,16 +510,16 @@ __global__ void __launch_bounds__(LDS ? 64 : 256) k_sim_resweep(SimResweepArgs a
 			const SweepCell o = sweep_chunk<false>(RS, RG, in, tc, mm, -1, t0, n, j, run0, gapf0, cy, mine, mine_nz, lane);
 			if (o.valid) { out |= outside(o.c) || outside(o.across) || outside(o.g); pos |= sim_score(o.c) > floor_score; }
 			if (t0 + 64 >= n) { const int l = n - 1 - t0; e.c = readlane64(o.c, l); e.d = readlane64(o.across, l); e.g = readlane64(o.g, l); }
-			budget--;
+			budget--; steps++;
 		}
 		e.any_out = __ballot(out) != 0;
 		if (__ballot(pos)) positive = true;
 		if (lane == 0) { CS[j] = e.c; CG[j] = e.g; }
 		wave_publish();
+		slice_over();
 		return e;
 	};
 
-	const int budget0 = budget;
 	long long tick = a.debug ? (long long)wall_clock64() : 0;
 	// ---- phase 0: backwards over the node's rectangle
 	if (phase == 0) {
@@ -559,8 +568,8 @@ __global__ void __launch_bounds__(LDS ? 64 : 256) k_sim_resweep(SimResweepArgs a
 			} else phase = 3;
 		}
 	}
-	if (a.debug) { const long long now = (long long)wall_clock64(); dbg_t[0] = now - tick; dbg_n[0] = budget0 - budget; tick = now; }
-	const int budget1 = budget;
+	if (a.debug) { const long long now = (long long)wall_clock64(); dbg_t[0] = now - tick; dbg_n[0] = steps; tick = now; }
+	const int steps1 = steps;
 	// ---- phase 2: forwards over the final rectangle, new nodes in row-major order (sim.h:1086-1141)
 	if (phase == 2) {
 		const int n = nn - n1;
@@ -577,7 +586,7 @@ __global__ void __launch_bounds__(LDS ? 64 : 256) k_sim_resweep(SimResweepArgs a
 				const ChunkIn in = nx;
 				if (t0 + 64 < n) nx = chunk_load(CS, CG, n1 + 1, 1, t0 + 64, n, tcu, lane);
 				const SweepCell o = sweep_chunk<true>(CS, CG, in, qc, n1 + 1, 1, t0, n, i, run0, gapf0, cy, mine, mine_nz, lane);
-				budget--;
+				budget--; steps++;
 				unsigned long long ev = __ballot(o.valid && sim_score(o.c) > floor_score);
 				if (ev) floor_score = 1;                         // min = addnode() (sim.h:1131): 1 from the first new cell on
 				const long long te = a.debug ? (long long)wall_clock64() : 0;
@@ -586,11 +595,12 @@ __global__ void __launch_bounds__(LDS ? 64 : 256) k_sim_resweep(SimResweepArgs a
 				if (a.debug) dbg_t[2] += (long long)wall_clock64() - te;
 			}
 			wave_publish();
+			slice_over();
 		}
 		if (i > mm) phase = 3;
 	}
 	if (a.debug && lane == 0) {
-		dbg_t[1] = (long long)wall_clock64() - tick; dbg_n[1] = budget1 - budget;
+		dbg_t[1] = (long long)wall_clock64() - tick; dbg_n[1] = steps - steps1;
 		atomicAdd((unsigned long long*)a.debug + 6, (unsigned long long)L.dbg_pass); atomicAdd((unsigned long long*)a.debug + 7, (unsigned long long)L.dbg_bad);
 		for (int k = 0; k < 3; k++) { atomicAdd((unsigned long long*)a.debug + 2 * k, (unsigned long long)dbg_n[k]); atomicAdd((unsigned long long*)a.debug + 2 * k + 1, (unsigned long long)dbg_t[k]); }
 	}
