@@ -33,7 +33,7 @@ int sim_forward_units(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, c
 		size_t free_b = 0, total_b = 0;
 		const size_t unit_b = (size_t)64 * cap * sizeof(SimEvent) + (size_t)2 * row_stride * sizeof(uint64_t);
 		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-			const size_t have = E->sim_ev.cap + free_b / 3;
+			const size_t have = std::min<size_t>((size_t)16 << 30, E->sim_ev.cap + free_b / 3);      // (ten workers may be doing this at once)
 			per_slice = (int)std::max<size_t>(256, std::min<size_t>(8192, have / unit_b));
 		}
 		const int nslices = (nrun + per_slice - 1) / per_slice;
@@ -107,7 +107,7 @@ int sim_resweep_rounds(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, 
 	{
 		size_t free_b = 0, total_b = 0;
 		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-			state_budget = std::max(state_budget, (E->sim_used.cap + E->sim_usedc.cap + E->sim_col.cap + E->sim_rowst.cap + free_b) / 4);
+			state_budget = std::max(state_budget, std::min<size_t>((size_t)24 << 30, (E->sim_used.cap + E->sim_usedc.cap + E->sim_col.cap + E->sim_rowst.cap + free_b) / 4));
 	}
 	const int slice = (int)std::max<size_t>(1, std::min<size_t>((size_t)cnt, state_budget / per_unit));
 	std::vector<SimRoundReq> req((size_t)slice);
@@ -124,7 +124,7 @@ int sim_resweep_rounds(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, 
 	fasim_sim_node* const hn = (fasim_sim_node*)E->pin_sim;
 	std::vector<int32_t> hc((size_t)slice), hf((size_t)slice), hp((size_t)slice);
 	std::vector<char> pend((size_t)slice);
-	// A unit's share of a launch: a time slice (50 ms while more than 1 024 units are active, 150 ms for the tail; the kernel reads
+	// A unit's share of a launch: a time slice (50 ms while more than 1 024 units are active, 60 ms for the tail; the kernel reads
 	// the clock every eighth line), or a number of 64-cell steps when FASIM_SIM_BUDGET is set (tests).  A unit that needs more (a
 	// re-sweep of most of the matrix) carries on in the next launch: the average round of H19 x 5 kb takes 10 k steps, the heaviest
 	// unit of a 500 kb record 12 M steps in all.
@@ -188,7 +188,7 @@ int sim_resweep_rounds(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, 
 			a.rowS = E->sim_rowst.as<uint64_t>(); a.rowG = a.rowS + (size_t)n * row_stride;
 			a.col_stride = col_stride; a.row_stride = row_stride;
 			a.nodes = E->sim_nodes.as<SimNodeDev>(); a.node_count = E->sim_cnt.as<int32_t>(); a.floor_out = E->sim_floor.as<int32_t>();
-			a.pending = E->sim_pending.as<int32_t>(); a.state = E->sim_state.as<SimSweepState>(); a.budget = budget_env ? budget_env : (1 << 20); a.slice_ticks = budget_env ? ((int64_t)1 << 40) : (active > 1024 ? 5000000 : 15000000); a.debug = debug ? E->sim_debug.as<uint64_t>() : nullptr;
+			a.pending = E->sim_pending.as<int32_t>(); a.state = E->sim_state.as<SimSweepState>(); a.budget = budget_env ? budget_env : (1 << 20); a.slice_ticks = budget_env ? ((int64_t)1 << 40) : (active > 1024 ? 5000000 : 6000000); a.debug = debug ? E->sim_debug.as<uint64_t>() : nullptr;
 			const double tl0 = now_s();
 			hipError_t he;
 			{ TimedScope ts(E, 7); he = launch_sim_resweep(a, active, active <= 256 /* one unit per CU: all at once */, E->st); }
