@@ -101,6 +101,7 @@ struct fasim_engine {
 	int host_threads_total = 1;
 	int host_threads_share_total = 1;            // (workers) the scan's total, for the share of a worker near the end of a scan
 	bool host_threads_explicit = false;          // FASIM_HOST_THREADS / option host_threads given: -F keeps to it too
+	std::atomic<int>* sim_in_flight = nullptr;      // (set for the duration of a scan) -F: units in re-sweep launches right now, over all workers
 	std::atomic<int>* active_workers = nullptr;  // (set for the duration of a scan) workers that still have batches: the host threads of
 	                                             // those that have run out go to the bursts of the others
 	int sim_threads = 1;                         // -F: host threads of this worker for the finish half (all cores shared by the batches in flight)

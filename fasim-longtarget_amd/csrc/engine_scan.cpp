@@ -132,6 +132,8 @@ int sim_resweep_rounds(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, 
 	const int budget_env = budget_s && atoi(budget_s) > 0 ? atoi(budget_s) : 0;
 	static const bool debug = getenv("FASIM_SIM_DEBUG") != nullptr;
 	long launches = 0, unit_launches = 0;
+	int contributed = 0;                                     // this batch's share of E->sim_in_flight
+	struct Leave { fasim_engine* E; int* c; ~Leave() { if (E->sim_in_flight && *c) E->sim_in_flight->fetch_sub(*c); } } leave{ E, &contributed };
 	if (debug) { HIPOK(E->sim_debug.ensure(128)); HIPOK(hipMemsetAsync(E->sim_debug.p, 0, 128, E->st)); }
 	ProfScope rounds_wall(31, "-F rounds (re-sweep launches + host half), wall");
 	for (int s0 = 0; s0 < cnt; s0 += slice) {
@@ -172,8 +174,13 @@ int sim_resweep_rounds(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, 
 				hc[(size_t)k] = (int32_t)nl.size();
 				std::copy(nl.begin(), nl.end(), hn + (size_t)k * FASIM_SIM_K);
 			}
-			if (!active) break;
+			if (!active) { if (E->sim_in_flight && contributed) { E->sim_in_flight->fetch_sub(contributed); contributed = 0; } break; }
 			launches++; unit_launches += active;
+			// units in flight over all the workers' batches: the LDS variant holds a CU per unit, so it is for the moments when the
+			// whole scan is down to its tail
+			int everywhere = active;
+			if (E->sim_in_flight) everywhere = E->sim_in_flight->fetch_add(active - contributed) + active - contributed;
+			contributed = active;
 			int rc = upload_async(E, E->sim_req, req.data(), sizeof(SimRoundReq) * n); if (rc) return rc;
 			rc = upload_async(E, E->sim_pairs, pairs.data(), sizeof(uint32_t) * pairs.size()); if (rc) return rc;
 			rc = upload_async(E, E->sim_active, act.data(), sizeof(int32_t) * act.size()); if (rc) return rc;
@@ -188,10 +195,10 @@ int sim_resweep_rounds(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, 
 			a.rowS = E->sim_rowst.as<uint64_t>(); a.rowG = a.rowS + (size_t)n * row_stride;
 			a.col_stride = col_stride; a.row_stride = row_stride;
 			a.nodes = E->sim_nodes.as<SimNodeDev>(); a.node_count = E->sim_cnt.as<int32_t>(); a.floor_out = E->sim_floor.as<int32_t>();
-			a.pending = E->sim_pending.as<int32_t>(); a.state = E->sim_state.as<SimSweepState>(); a.budget = budget_env ? budget_env : (1 << 20); a.slice_ticks = budget_env ? ((int64_t)1 << 40) : (active > 1024 ? 5000000 : 6000000); a.debug = debug ? E->sim_debug.as<uint64_t>() : nullptr;
+			a.pending = E->sim_pending.as<int32_t>(); a.state = E->sim_state.as<SimSweepState>(); a.budget = budget_env ? budget_env : (1 << 20); a.slice_ticks = budget_env ? ((int64_t)1 << 40) : (everywhere > 1024 ? 5000000 : 6000000); a.debug = debug ? E->sim_debug.as<uint64_t>() : nullptr;
 			const double tl0 = now_s();
 			hipError_t he;
-			{ TimedScope ts(E, 7); he = launch_sim_resweep(a, active, active <= 256 /* one unit per CU: all at once */, E->st); }
+			{ TimedScope ts(E, 7); he = launch_sim_resweep(a, active, everywhere <= 256 /* one unit per CU: all at once */, E->st); }
 			if (he != hipSuccess) return fail(E, FASIM_E_HIP, "sim_resweep launch failed: %s", hipGetErrorString(he));
 			HIPOK(hipMemcpyAsync(hc.data(), E->sim_cnt.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, E->st));
 			HIPOK(hipMemcpyAsync(hf.data(), E->sim_floor.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, E->st));
@@ -591,7 +598,7 @@ int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rna_lens,
 			int rc = fasim_engine_create(E->device, &w); if (rc) return fail(E, rc, "cannot create worker engine: %s", fasim_last_error(nullptr));
 			E->workers.push_back(w);
 		}
-		std::atomic<int> active_workers(nworkers);
+		std::atomic<int> active_workers(nworkers), sim_active(0);
 		std::vector<fasim_engine*> ws(1, E);
 		for (int k = 0; k < nworkers - 1; k++) ws.push_back(E->workers[k]);
 		{
@@ -603,7 +610,7 @@ int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rna_lens,
 			w->scan_v1 = E->scan_v1; w->align_v1 = E->align_v1;
 			w->hz_chunks = E->hz_chunks; w->hz_snap = E->hz_snap; w->hz_target = E->hz_target; w->hz_hot_w = E->hz_hot_w; w->opt_band = E->opt_band;
 			w->host_threads = std::max(1, E->host_threads_total / nworkers);
-			w->host_threads_share_total = E->host_threads_total; w->active_workers = &active_workers;
+			w->host_threads_share_total = E->host_threads_total; w->active_workers = &active_workers; w->sim_in_flight = &sim_active;
 			{
 				// -F: the finish half of classic SIM is ~40 ms of host work per unit and nothing else needs the cores meanwhile
 				const int all = E->host_threads_explicit ? E->host_threads_total : usable_cores();
@@ -654,7 +661,7 @@ int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rna_lens,
 		const double t_workers = now_s();
 		if (ws.size() == 1) run(0);
 		else { std::vector<std::thread> th; for (size_t wi = 0; wi < ws.size(); wi++) th.emplace_back(run, wi); for (auto& t : th) t.join(); }
-		for (fasim_engine* w : ws) w->active_workers = nullptr;
+		for (fasim_engine* w : ws) { w->active_workers = nullptr; w->sim_in_flight = nullptr; }
 		if (g_prof.on) fprintf(stderr, "[fasim prof] scan workers                                  %.3f s\n", now_s() - t_workers);
 		for (size_t wi = 0; wi < ws.size(); wi++) if (wrc[wi]) { if (ws[wi] != E) E->err = ws[wi]->err; return wrc[wi]; }
 		// a multi-query call leaves the engine on its LAST query (documented in fasim_hip.h)
