@@ -156,7 +156,7 @@ def cpu_baseline(rna_path, m, slices):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--dna-mb", type=float, default=50.0, help="million nt of synthetic DNA per rank (default 50)")
     ap.add_argument("--dna", choices=["random", "genome", "planted"], default="random")
