@@ -473,7 +473,7 @@ static int records_to_list(const fasim_triplex* recs, int64_t count, const char*
 		t.tfo = pool ? pool + r.tfo_off : ""; t.tts = pool ? pool + r.tts_off : "";
 		// records of a later FASTA record in the reference's accumulating reader carry their own genome start (main(),
 		// Fasim-LongTarget.cpp:141-149 patches each record's triplexes with startGenomeTmp[i])
-		if (r.genome_shift != 0) { t.genomestart = (long)r.starj + (long)start_genome + r.genome_shift - 1; t.genomeend = (long)r.endj + (long)start_genome + r.genome_shift - 1; }
+		if (r.genome_shift != 0) { t.genomestart = (long)r.starj + (long)start_genome + r.genome_shift - 1; t.genomeend = (long)r.endj + (long)start_genome + r.genome_shift - 1; t.genome_set = true; }
 		if (t.nt > p->cLength && (t.stari + t.endi) / 2 - p->cDistance < 0 && !(flags & FASIM_TAIL_CLAMP_CLUSTER))
 			return fail(nullptr, FASIM_E_UNSUPPORTED, "a triplex mid-point lies within -ds of the query start: the reference's clustering does not terminate for this input (FASIM_TAIL_CLAMP_CLUSTER / fasim --clamp-cluster gives a defined result)");
 	}

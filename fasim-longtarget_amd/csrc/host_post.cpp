@@ -405,7 +405,7 @@ static inline void put_int(std::string& o, long v) { char b[24]; const int n = s
 std::string tfosorted_text(std::vector<HostTriplex>& list, const std::string& chr, long start_genome, const fasim_params& p)
 {
 	for (HostTriplex& t : list) {                 // main(): Fasim-LongTarget.cpp:141-149
-		if (t.genomestart == 0) { t.genomestart = t.starj + start_genome - 1; t.genomeend = t.endj + start_genome - 1; }
+		if (!t.genome_set) { t.genomestart = t.starj + start_genome - 1; t.genomeend = t.endj + start_genome - 1; t.genome_set = true; }
 	}
 	cluster_triplex(p.cDistance, p.cLength, list);
 	std::sort(list.begin(), list.end(), by_motif); // Fasim-LongTarget.cpp:813 (unstable, same algorithm)

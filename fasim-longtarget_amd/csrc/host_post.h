@@ -39,6 +39,7 @@ struct HostTriplex {
 	int cand = -1;                 // caller's index of the alignment this record came from (strings are filled in later)
 	int middle = 0, center = 0, motif = 0, neartriplex = 0;
 	long genomestart = 0, genomeend = 0;
+	bool genome_set = false;          // genomestart / genomeend were filled in by the caller (accumulate mode: shifted coordinates, which may be 0)
 };
 
 // convertMyTriplex (fastsim.h:291-414): appends to `list` when nt >= ntMin
