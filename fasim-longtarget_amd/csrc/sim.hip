@@ -23,7 +23,6 @@
 // Integer DP: no MFMA.  Plain 64-bit VALU arithmetic, not yet tuned.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 #include "kernels.h"
 
 namespace fasim {
@@ -632,10 +631,9 @@ hipError_t launch_sim_resweep(const SimResweepArgs& a, int32_t nunit, bool few_u
 	if (nunit <= 0) return hipSuccess;
 	// the lines' states of one unit: 16 B per target column and per query row; in LDS when that fits one CU's 160 KB (minus a margin)
 	const size_t lds = (size_t)(2 * a.col_stride + 2 * a.row_stride) * sizeof(uint64_t);
-	static const bool want_lds = [] { const char* e = getenv("FASIM_SIM_LDS"); return e ? atoi(e) != 0 : true; }();
 	// LDS variant: one unit per CU at a time, each 3-5 x faster -- for the launches in which few units are left (the tail of the
 	// heaviest units); with thousands of units active the 4-units-per-workgroup variant keeps every wave slot of the chip busy
-	if (want_lds && few_units && lds <= 150 * 1024) {
+	if (few_units && lds <= 150 * 1024) {
 		static bool attr_set = false;
 		if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_sim_resweep<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
 		hipLaunchKernelGGL(k_sim_resweep<true>, dim3((unsigned)nunit), dim3(64), lds, st, a, nunit);
