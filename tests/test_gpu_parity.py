@@ -818,6 +818,10 @@ def test_classic_sim_resweep_self_check(mod, h19, golden_dir, monkeypatch):
     monkeypatch.delenv("FASIM_SIM_RESWEEP")
     res = e.scan(dna, p)
     assert res.triplexes() == exp and res.stats["kernel_launches"][7] > 1
+    # several batches in flight on the worker engines (their re-sweep launches overlap; the kernel variant follows the units in
+    # flight over all of them)
+    e.set_option("seg_batch", 1)
+    assert e.scan(dna, p).triplexes() == exp
     e.close()
 
 
