@@ -101,6 +101,7 @@ struct fasim_engine {
 	int host_threads_total = 1;
 	int host_threads_share_total = 1;            // (workers) the scan's total, for the share of a worker near the end of a scan
 	bool host_threads_explicit = false;          // FASIM_HOST_THREADS / option host_threads given: -F keeps to it too
+	int scan_workers = 1;                        // worker engines of the scan in progress (they share the HBM)
 	std::atomic<int>* sim_in_flight = nullptr;      // (set for the duration of a scan) -F: units in re-sweep launches right now, over all workers
 	std::atomic<int>* active_workers = nullptr;  // (set for the duration of a scan) workers that still have batches: the host threads of
 	                                             // those that have run out go to the bursts of the others

@@ -33,7 +33,8 @@ int sim_forward_units(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, c
 		size_t free_b = 0, total_b = 0;
 		const size_t unit_b = (size_t)64 * cap * sizeof(SimEvent) + (size_t)2 * row_stride * sizeof(uint64_t);
 		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-			const size_t have = std::min<size_t>((size_t)16 << 30, E->sim_ev.cap + free_b / 3);      // (ten workers may be doing this at once)
+			// (all the workers may be doing this at once: a fixed share of 96 GB each, whatever hipMemGetInfo says at the moment)
+			const size_t have = std::min<size_t>(((size_t)96 << 30) / (size_t)std::max(1, E->scan_workers), E->sim_ev.cap + free_b / 3);
 			per_slice = (int)std::max<size_t>(256, std::min<size_t>(8192, have / unit_b));
 		}
 		const int nslices = (nrun + per_slice - 1) / per_slice;
@@ -107,7 +108,7 @@ int sim_resweep_rounds(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, 
 	{
 		size_t free_b = 0, total_b = 0;
 		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-			state_budget = std::max(state_budget, std::min<size_t>((size_t)24 << 30, (E->sim_used.cap + E->sim_usedc.cap + E->sim_col.cap + E->sim_rowst.cap + free_b) / 4));
+			state_budget = std::max(state_budget, std::min<size_t>(((size_t)96 << 30) / (size_t)std::max(1, E->scan_workers), (E->sim_used.cap + E->sim_usedc.cap + E->sim_col.cap + E->sim_rowst.cap + free_b) / 4));
 	}
 	const int slice = (int)std::max<size_t>(1, std::min<size_t>((size_t)cnt, state_budget / per_unit));
 	std::vector<SimRoundReq> req((size_t)slice);
@@ -610,7 +611,7 @@ int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rna_lens,
 			w->scan_v1 = E->scan_v1; w->align_v1 = E->align_v1;
 			w->hz_chunks = E->hz_chunks; w->hz_snap = E->hz_snap; w->hz_target = E->hz_target; w->hz_hot_w = E->hz_hot_w; w->opt_band = E->opt_band;
 			w->host_threads = std::max(1, E->host_threads_total / nworkers);
-			w->host_threads_share_total = E->host_threads_total; w->active_workers = &active_workers; w->sim_in_flight = &sim_active;
+			w->host_threads_share_total = E->host_threads_total; w->active_workers = &active_workers; w->sim_in_flight = &sim_active; w->scan_workers = (int)ws.size();
 			{
 				// -F: the finish half of classic SIM is ~40 ms of host work per unit and nothing else needs the cores meanwhile
 				const int all = E->host_threads_explicit ? E->host_threads_total : usable_cores();
@@ -661,7 +662,7 @@ int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rna_lens,
 		const double t_workers = now_s();
 		if (ws.size() == 1) run(0);
 		else { std::vector<std::thread> th; for (size_t wi = 0; wi < ws.size(); wi++) th.emplace_back(run, wi); for (auto& t : th) t.join(); }
-		for (fasim_engine* w : ws) { w->active_workers = nullptr; w->sim_in_flight = nullptr; }
+		for (fasim_engine* w : ws) { w->active_workers = nullptr; w->sim_in_flight = nullptr; w->scan_workers = 1; }
 		if (g_prof.on) fprintf(stderr, "[fasim prof] scan workers                                  %.3f s\n", now_s() - t_workers);
 		for (size_t wi = 0; wi < ws.size(); wi++) if (wrc[wi]) { if (ws[wi] != E) E->err = ws[wi]->err; return wrc[wi]; }
 		// a multi-query call leaves the engine on its LAST query (documented in fasim_hip.h)
