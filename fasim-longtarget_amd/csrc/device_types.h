@@ -90,22 +90,23 @@ struct SimFwdArgs {
 };
 
 // ---- row f3: the re-sweeps of classic SIM between the K rounds (sim.hip, k_sim_resweep) --------------------------------------
-struct SimRoundReq { int32_t active, m1, mm, n1, nn, floor_score, pairs_first, pairs_count; };   // active: 1 = new round (bounding box of its node, its traceback's used pairs), 2 = carry on
+struct SimRoundReq { int32_t active, m1, mm, n1, nn, floor_score, pairs_first, pairs_count, unit, node_count; };   // active: 1 = new round (bounding box of its node, its traceback's used pairs), 2 = carry on
+struct SimRoundOut { int32_t node_count, floor_score, pending, pad; };   // floor_score = the reference's `min` after the round (0, then 1); pending: out of time, to be continued
 struct SimSweepState { int32_t phase, i, m1, n1, rl, cl, floor_score, nround, grow_rows, grow_cols, positive, pad; };   // an unfinished re-sweep between two launches
 struct SimResweepArgs {
 	const uint8_t* tcodes; const int32_t* unit_len; int32_t tstride;
 	const uint8_t* qcodes; int32_t m;
-	const int32_t* active_idx;      // [launched slots]: the units this launch works on
-	const SimRoundReq* req;         // [unit]
+	const SimRoundReq* req;         // [slot]: the units this launch works on (unit = index into the per-unit arrays below)
+	const SimNodeDev* nodes_in;     // [slot][SIM_K]: node list of a unit that starts a round (req.node_count entries)
+	SimNodeDev* nodes_out;          // [slot][SIM_K] + out[slot]: what the host reads back
+	SimRoundOut* out;
 	const uint32_t* pairs;          // (query row << 16) | target column, 1-based, of all units' requests
 	uint16_t* usedc;                // [unit][col_stride][SIM_K]: the same per target column (the query row aligned to it)
 	uint16_t* used; int32_t* used_cnt;   // [unit][m + 2][SIM_K]: per query row and round the target column aligned to it (0 = none); [unit]: rounds swept so far
 	uint64_t* colS; uint64_t* colG; // [unit][col_stride]: per target column the DP state across the sweep line (CC/RR/EE and DD/SS/FF of sim.h as one key each)
 	uint64_t* rowS; uint64_t* rowG; // [unit][row_stride]: per query row (HH/II/JJ and WW/XX/YY)
 	int64_t col_stride, row_stride;
-	SimNodeDev* nodes; int32_t* node_count;      // [unit][SIM_K] in / out, list order = lane order
-	int32_t* floor_out;             // [unit]: the reference's `min` after the round (0, then 1)
-	int32_t* pending;               // [unit]: 1 = out of budget, to be continued
+	SimNodeDev* nodes; int32_t* node_count;      // [unit][SIM_K]: where a suspended unit's list waits for the next launch
 	SimSweepState* state;           // [unit]
 	int32_t budget;                 // at most this many 64-cell steps per unit and launch ...
 	int64_t slice_ticks;            // ... and this much time (100 MHz ticks): what normally ends a unit's share of a launch

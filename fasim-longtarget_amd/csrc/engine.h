@@ -88,7 +88,7 @@ struct fasim_engine {
 		fprobs, ftasks, fstream, fout, aout, cigpool, cigcount, forder, scratch2, boundary, fboundary, unit_hz,
 		unit_first, hz_cols, hz_plan, hz_base, hz_items, snap, hz_state, hz_rows, hz_chunk, hz_src, hz_zero,   // chunked hazard re-run
 		qsim, sim_min, sim_row, sim_ev, sim_cnt, sim_nodes,      // -F: query codes of the SIM alphabet, thresholds, strip row buffer, events, counters
-		sim_req, sim_pairs, sim_used, sim_rounds, sim_col, sim_rowst, sim_floor, sim_pending, sim_state, sim_usedc, sim_debug, sim_active;   // -F re-sweeps: per-round requests, used pairs, DP state per column / row
+		sim_req, sim_pairs, sim_used, sim_rounds, sim_col, sim_rowst, sim_state, sim_usedc, sim_debug, sim_nodes_in, sim_nodes_out, sim_out;   // -F re-sweeps: per-round requests, used pairs, DP state per column / row
 	bool align_v1 = false;        // FASIM_ALIGN_V1=1: force the stripe-faithful kernels for stage 3
 	std::vector<fasim_engine*> workers;   // extra engines on the same device: batches in flight concurrently
 	// Gate for the two GPU-filling kernels (k_scan, k_align_fwd).  Without it the workers fall into lock step: all of them

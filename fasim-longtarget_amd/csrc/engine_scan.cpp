@@ -123,7 +123,8 @@ int sim_resweep_rounds(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, 
 		E->pin_sim_cap = hn_bytes;
 	}
 	fasim_sim_node* const hn = (fasim_sim_node*)E->pin_sim;
-	std::vector<int32_t> hc((size_t)slice), hf((size_t)slice), hp((size_t)slice);
+	std::vector<SimRoundReq> rq;
+	std::vector<SimRoundOut> ho;
 	std::vector<char> pend((size_t)slice);
 	// A unit's share of a launch: a time slice (50 ms while more than 1 024 units are active, 60 ms for the tail; the kernel reads
 	// the clock every eighth line), or a number of 64-cell steps when FASIM_SIM_BUDGET is set (tests).  A unit that needs more (a
@@ -141,13 +142,14 @@ int sim_resweep_rounds(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, 
 		const int n = std::min(slice, cnt - s0);
 		HIPOK(E->sim_used.ensure(used_per_unit * n)); HIPOK(E->sim_rounds.ensure(sizeof(int32_t) * n));
 		HIPOK(E->sim_col.ensure((size_t)n * 2 * col_stride * sizeof(uint64_t))); HIPOK(E->sim_rowst.ensure((size_t)n * 2 * row_stride * sizeof(uint64_t)));
-		HIPOK(E->sim_floor.ensure(sizeof(int32_t) * n)); HIPOK(E->sim_cnt.ensure(sizeof(int32_t) * n));
+		HIPOK(E->sim_out.ensure(sizeof(SimRoundOut) * n)); HIPOK(E->sim_cnt.ensure(sizeof(int32_t) * n));
+		HIPOK(E->sim_nodes_in.ensure(sizeof(SimNodeDev) * (size_t)n * SIM_K)); HIPOK(E->sim_nodes_out.ensure(sizeof(SimNodeDev) * (size_t)n * SIM_K));
 		HIPOK(E->sim_nodes.ensure(sizeof(SimNodeDev) * (size_t)n * SIM_K)); HIPOK(E->sim_req.ensure(sizeof(SimRoundReq) * n));
 		HIPOK(hipMemsetAsync(E->sim_used.p, 0, used_per_unit * n, E->st));
 		HIPOK(E->sim_usedc.ensure(usedc_per_unit * n));
 		HIPOK(hipMemsetAsync(E->sim_usedc.p, 0, usedc_per_unit * n, E->st));
 		HIPOK(hipMemsetAsync(E->sim_rounds.p, 0, sizeof(int32_t) * n, E->st));
-		HIPOK(E->sim_pending.ensure(sizeof(int32_t) * n)); HIPOK(E->sim_state.ensure(sizeof(SimSweepState) * n));
+		HIPOK(E->sim_state.ensure(sizeof(SimSweepState) * n));
 		std::fill(pend.begin(), pend.end(), 0);
 		for (;;) {
 			double t0 = now_s();
@@ -162,18 +164,20 @@ int sim_resweep_rounds(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, 
 				req[(size_t)k] = r;
 			});
 			g_prof.add(30, "-F rounds: host half (best node, traceback, record), wall", now_s() - t0);
-			pairs.clear(); act.clear();
+			pairs.clear(); act.clear(); rq.clear();
 			int active = 0;
 			for (int k = 0; k < n; k++) {
 				SimRoundReq& r = req[(size_t)k];
-				if (!r.active) { hc[(size_t)k] = 0; continue; }
-				active++; act.push_back(k);
-				if (r.active == 2) continue;                    // its node list is the one the last launch left
-				r.pairs_first = (int32_t)pairs.size(); r.pairs_count = (int32_t)np[(size_t)k].size();
-				for (const auto& pr : np[(size_t)k]) pairs.push_back(((uint32_t)pr.first << 16) | (uint32_t)pr.second);
-				const std::vector<fasim_sim_node>& nl = units[s0 + k]->nodes;
-				hc[(size_t)k] = (int32_t)nl.size();
-				std::copy(nl.begin(), nl.end(), hn + (size_t)k * FASIM_SIM_K);
+				if (!r.active) continue;
+				r.unit = k;
+				if (r.active == 1) {
+					r.pairs_first = (int32_t)pairs.size(); r.pairs_count = (int32_t)np[(size_t)k].size();
+					for (const auto& pr : np[(size_t)k]) pairs.push_back(((uint32_t)pr.first << 16) | (uint32_t)pr.second);
+					const std::vector<fasim_sim_node>& nl = units[s0 + k]->nodes;
+					r.node_count = (int32_t)nl.size();
+					std::copy(nl.begin(), nl.end(), hn + (size_t)active * FASIM_SIM_K);       // slot = position among the active units
+				}                                                                                 // (active == 2: its list waits on the device)
+				active++; act.push_back(k); rq.push_back(r);
 			}
 			if (!active) { if (E->sim_in_flight && contributed) { E->sim_in_flight->fetch_sub(contributed); contributed = 0; } break; }
 			launches++; unit_launches += active;
@@ -182,50 +186,53 @@ int sim_resweep_rounds(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, 
 			int everywhere = active;
 			if (E->sim_in_flight) everywhere = E->sim_in_flight->fetch_add(active - contributed) + active - contributed;
 			contributed = active;
-			int rc = upload_async(E, E->sim_req, req.data(), sizeof(SimRoundReq) * n); if (rc) return rc;
+			// per launch only the active units' requests and node lists cross PCIe (a finished or suspended unit costs nothing)
+			int rc = upload_async(E, E->sim_req, rq.data(), sizeof(SimRoundReq) * active); if (rc) return rc;
 			rc = upload_async(E, E->sim_pairs, pairs.data(), sizeof(uint32_t) * pairs.size()); if (rc) return rc;
-			rc = upload_async(E, E->sim_active, act.data(), sizeof(int32_t) * act.size()); if (rc) return rc;
-			HIPOK(hipMemcpyAsync(E->sim_cnt.p, hc.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, E->st));
-			HIPOK(hipMemcpyAsync(E->sim_nodes.p, hn, sizeof(fasim_sim_node) * (size_t)n * FASIM_SIM_K, hipMemcpyHostToDevice, E->st));
+			HIPOK(hipMemcpyAsync(E->sim_nodes_in.p, hn, sizeof(fasim_sim_node) * (size_t)active * FASIM_SIM_K, hipMemcpyHostToDevice, E->st));
 			SimResweepArgs a;
 			a.tcodes = tcodes_dev + (size_t)(first + s0) * tstride; a.unit_len = unit_len_dev + first + s0; a.tstride = tstride;
 			a.qcodes = E->qsim.as<uint8_t>(); a.m = M;
-			a.active_idx = E->sim_active.as<int32_t>(); a.req = E->sim_req.as<SimRoundReq>(); a.pairs = E->sim_pairs.as<uint32_t>();
+			a.req = E->sim_req.as<SimRoundReq>(); a.pairs = E->sim_pairs.as<uint32_t>();
+			a.nodes_in = E->sim_nodes_in.as<SimNodeDev>(); a.nodes_out = E->sim_nodes_out.as<SimNodeDev>(); a.out = E->sim_out.as<SimRoundOut>();
 			a.used = E->sim_used.as<uint16_t>(); a.usedc = E->sim_usedc.as<uint16_t>(); a.used_cnt = E->sim_rounds.as<int32_t>();
 			a.colS = E->sim_col.as<uint64_t>(); a.colG = a.colS + (size_t)n * col_stride;
 			a.rowS = E->sim_rowst.as<uint64_t>(); a.rowG = a.rowS + (size_t)n * row_stride;
 			a.col_stride = col_stride; a.row_stride = row_stride;
-			a.nodes = E->sim_nodes.as<SimNodeDev>(); a.node_count = E->sim_cnt.as<int32_t>(); a.floor_out = E->sim_floor.as<int32_t>();
-			a.pending = E->sim_pending.as<int32_t>(); a.state = E->sim_state.as<SimSweepState>(); a.budget = budget_env ? budget_env : (1 << 20); a.slice_ticks = budget_env ? ((int64_t)1 << 40) : (everywhere > 1024 ? 5000000 : 6000000); a.debug = debug ? E->sim_debug.as<uint64_t>() : nullptr;
+			a.nodes = E->sim_nodes.as<SimNodeDev>(); a.node_count = E->sim_cnt.as<int32_t>();
+			a.state = E->sim_state.as<SimSweepState>(); a.budget = budget_env ? budget_env : (1 << 20); a.slice_ticks = budget_env ? ((int64_t)1 << 40) : (everywhere > 1024 ? 5000000 : 6000000); a.debug = debug ? E->sim_debug.as<uint64_t>() : nullptr;
 			const double tl0 = now_s();
 			hipError_t he;
 			{ TimedScope ts(E, 7); he = launch_sim_resweep(a, active, everywhere <= 256 /* one unit per CU: all at once */, E->st); }
 			if (he != hipSuccess) return fail(E, FASIM_E_HIP, "sim_resweep launch failed: %s", hipGetErrorString(he));
-			HIPOK(hipMemcpyAsync(hc.data(), E->sim_cnt.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, E->st));
-			HIPOK(hipMemcpyAsync(hf.data(), E->sim_floor.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, E->st));
-			HIPOK(hipMemcpyAsync(hp.data(), E->sim_pending.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, E->st));
-			HIPOK(hipMemcpyAsync(hn, E->sim_nodes.p, sizeof(fasim_sim_node) * (size_t)n * FASIM_SIM_K, hipMemcpyDeviceToHost, E->st));
+			ho.resize((size_t)active);
+			HIPOK(hipMemcpyAsync(ho.data(), E->sim_out.p, sizeof(SimRoundOut) * active, hipMemcpyDeviceToHost, E->st));
+			HIPOK(hipMemcpyAsync(hn, E->sim_nodes_out.p, sizeof(fasim_sim_node) * (size_t)active * FASIM_SIM_K, hipMemcpyDeviceToHost, E->st));
 			HIPOK(hipStreamSynchronize(E->st));
-			for (int k = 0; k < n; k++) if (req[(size_t)k].active && (hc[(size_t)k] < 0 || hc[(size_t)k] > FASIM_SIM_K)) return fail(E, FASIM_E_HIP, "sim_resweep: bad node count");
-			for (int k = 0; k < n; k++) pend[(size_t)k] = req[(size_t)k].active && hp[(size_t)k] != 0;
-			if (debug) { int np_ = 0; for (int k = 0; k < n; k++) np_ += pend[(size_t)k]; fprintf(stderr, "[fasim sim] launch %ld: %d active, %d suspended, budget %d, %.1f ms\n", launches, active, np_, a.budget, 1e3 * (now_s() - tl0)); }
+			int suspended = 0;
+			for (int s = 0; s < active; s++) {
+				if (ho[(size_t)s].node_count < 0 || ho[(size_t)s].node_count > FASIM_SIM_K) return fail(E, FASIM_E_HIP, "sim_resweep: bad node count");
+				pend[(size_t)act[(size_t)s]] = ho[(size_t)s].pending != 0;
+				suspended += ho[(size_t)s].pending != 0;
+			}
+			if (debug) fprintf(stderr, "[fasim sim] launch %ld: %d active, %d suspended, %.1f ms\n", launches, active, suspended, 1e3 * (now_s() - tl0));
 			if (mode == 2) {
 				std::atomic<int> bad(-1);
-				parallel_units(n, nthreads, [&](int k) {
-					if (!req[(size_t)k].active || pend[(size_t)k]) return;
-					SimUnit& U = *units[s0 + k];
-					const fasim_sim_node* dn = hn + (size_t)k * FASIM_SIM_K;
+				parallel_units(active, nthreads, [&](int s) {
+					if (ho[(size_t)s].pending) return;
+					SimUnit& U = *units[s0 + act[(size_t)s]];
+					const fasim_sim_node* dn = hn + (size_t)s * FASIM_SIM_K;
 					U.resweep_host();
-					if ((int)U.nodes.size() != hc[(size_t)k] || U.floor_score != hf[(size_t)k] || memcmp(U.nodes.data(), dn, sizeof(fasim_sim_node) * U.nodes.size())) bad.store(k);
+					if ((int)U.nodes.size() != ho[(size_t)s].node_count || U.floor_score != ho[(size_t)s].floor_score || memcmp(U.nodes.data(), dn, sizeof(fasim_sim_node) * U.nodes.size())) bad.store(act[(size_t)s]);
 				});
 				if (bad.load() >= 0) return fail(E, FASIM_E_HIP, "sim_resweep self-check: unit %d differs from the host re-sweep", first + s0 + bad.load());
 				continue;
 			}
-			for (int k = 0; k < n; k++) {
-				if (!req[(size_t)k].active || pend[(size_t)k]) continue;
-				const fasim_sim_node* dn = hn + (size_t)k * FASIM_SIM_K;
-				units[s0 + k]->nodes.assign(dn, dn + hc[(size_t)k]);
-				units[s0 + k]->floor_score = hf[(size_t)k];
+			for (int s = 0; s < active; s++) {
+				if (ho[(size_t)s].pending) continue;
+				const fasim_sim_node* dn = hn + (size_t)s * FASIM_SIM_K;
+				units[s0 + act[(size_t)s]]->nodes.assign(dn, dn + ho[(size_t)s].node_count);
+				units[s0 + act[(size_t)s]]->floor_score = ho[(size_t)s].floor_score;
 			}
 		}
 	}

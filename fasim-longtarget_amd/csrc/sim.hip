@@ -411,9 +411,9 @@ __global__ void __launch_bounds__(LDS ? 64 : 256) k_sim_resweep(SimResweepArgs a
 	// units of a batch tend to be the same few of the 48 encodings (unit = segment x 48 + encoding), i.e. the same XCDs
 	const int slot = LDS ? (int)blockIdx.x : (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
 	if (slot >= nunit) return;
-	const int unit = a.active_idx[slot];
+	const SimRoundReq rq = a.req[slot];
+	const int unit = rq.unit;
 	const int lane = threadIdx.x & 63;
-	const SimRoundReq rq = a.req[unit];
 	if (!rq.active) return;
 	const int M = a.m;
 	const int ustride = M + 2, cstride = (int)a.col_stride;
@@ -429,7 +429,8 @@ __global__ void __launch_bounds__(LDS ? 64 : 256) k_sim_resweep(SimResweepArgs a
 	const int mm = rq.mm, nn = rq.nn;
 	// node list: lane k < cnt holds node k
 	NodeList L;
-	nodes_load(L, lane, a.nodes + (int64_t)unit * SIM_K, a.node_count[unit]);
+	if (rq.active == 1) nodes_load(L, lane, a.nodes_in + (int64_t)slot * SIM_K, rq.node_count);
+	else nodes_load(L, lane, a.nodes + (int64_t)unit * SIM_K, a.node_count[unit]);
 	int phase, i, m1, n1, rl, cl, floor_score, nround;
 	bool grow_rows, grow_cols, positive;
 	if (rq.active == 1) {
@@ -603,9 +604,11 @@ __global__ void __launch_bounds__(LDS ? 64 : 256) k_sim_resweep(SimResweepArgs a
 		atomicAdd((unsigned long long*)a.debug + 6, (unsigned long long)L.dbg_pass); atomicAdd((unsigned long long*)a.debug + 7, (unsigned long long)L.dbg_bad);
 		for (int k = 0; k < 3; k++) { atomicAdd((unsigned long long*)a.debug + 2 * k, (unsigned long long)dbg_n[k]); atomicAdd((unsigned long long*)a.debug + 2 * k + 1, (unsigned long long)dbg_t[k]); }
 	}
-	nodes_store(L, lane, a.nodes + (int64_t)unit * SIM_K);
+	nodes_store(L, lane, phase != 3 ? a.nodes + (int64_t)unit * SIM_K : a.nodes_out + (int64_t)slot * SIM_K);
 	if (lane == 0) {
-		a.node_count[unit] = L.cnt; a.floor_out[unit] = floor_score; a.used_cnt[unit] = nround; a.pending[unit] = phase != 3;
+		SimRoundOut ro; ro.node_count = L.cnt; ro.floor_score = floor_score; ro.pending = phase != 3; ro.pad = 0;
+		a.out[slot] = ro;
+		a.node_count[unit] = L.cnt; a.used_cnt[unit] = nround;
 		if (phase != 3) {
 			SimSweepState st;
 			st.phase = phase; st.i = i; st.m1 = m1; st.n1 = n1; st.rl = rl; st.cl = cl; st.floor_score = floor_score; st.nround = nround;
