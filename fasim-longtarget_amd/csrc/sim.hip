@@ -89,6 +89,7 @@ struct NodeList {
 	int low; unsigned long long low_mask;                     // valid while cnt == SIM_K (nodes_add keeps them exact)
 	int junk, l2;                                             // batch path: the first node of lowest score; a lower bound of all other scores
 	int dbg_pass, dbg_bad;                                    // FASIM_SIM_DEBUG counters
+	uint32_t* bits;                                           // LDS, SIM_BITS bits: hash set of the start points of all nodes but the junk slot
 };
 __device__ __forceinline__ void nodes_find_low(NodeList& L, int lane)
 {
@@ -121,6 +122,12 @@ __device__ __forceinline__ void nodes_add(NodeList& L, int lane, int c, int star
 	else if (c > L.low) { L.low_mask &= ~(1ull << t); if (!L.low_mask) nodes_find_low(L, lane); }
 }
 
+// The batch path asks for every event whether its start point is one of the 49 other nodes': 49 compares per step, nearly always
+// in vain (0.7 % of the events of a random record hit).  A hash set of those start points in LDS (16 K bits per wave, rebuilt
+// whenever the roles change) answers "none of them" for the whole step with one LDS read per event in most steps.
+constexpr int SIM_BITS_LOG = 14, SIM_BITS_WORDS = (1 << SIM_BITS_LOG) / 32;
+__device__ __forceinline__ uint32_t start_hash(int start) { return ((uint32_t)start * 0x9E3779B1u) >> (32 - SIM_BITS_LOG); }
+
 // (junk, l2) for the batch path, from an exact (low, low_mask)
 __device__ __forceinline__ void nodes_steady(NodeList& L, int lane)
 {
@@ -130,6 +137,11 @@ __device__ __forceinline__ void nodes_steady(NodeList& L, int lane)
 	unsigned v = (lane < L.cnt && lane != t) ? (unsigned)L.score : 0xffffffffu;
 	for (int o = 32; o; o >>= 1) { const unsigned w = (unsigned)__shfl_xor((int)v, o, 64); v = w < v ? w : v; }
 	L.junk = t; L.l2 = (int)v;
+	// the hash set of the others' start points, from scratch (the roles change on 3 % of the steps)
+	for (int w = lane; w < SIM_BITS_WORDS; w += 64) L.bits[w] = 0;
+	__builtin_amdgcn_s_waitcnt(0);
+	if (lane < L.cnt && lane != t) { const uint32_t h = start_hash(L.start); atomicOr(&L.bits[h >> 5], 1u << (h & 31)); }
+	__builtin_amdgcn_s_waitcnt(0);
 }
 
 // Up to 64 events of ONE row in column order (lane order), has = this lane carries one.  With a full list whose first lowest node
@@ -154,7 +166,8 @@ __device__ __forceinline__ void nodes_add_batch(NodeList& L, int lane, bool has,
 		L.dbg_pass++;
 		const bool mine = (todo >> lane) & 1;
 		int hit = -1;
-		{
+		const uint32_t hs = start_hash(start);
+		if (__ballot(mine && ((L.bits[hs >> 5] >> (hs & 31)) & 1))) {
 			const int others = lane == t ? -1 : L.start;                // -1 is no start point (rows and columns stay below 65535)
 #pragma unroll
 			for (int k = 0; k < SIM_K; k++) { const int sk = __builtin_amdgcn_readlane(others, k); hit = start == sk ? k : hit; }
@@ -208,8 +221,9 @@ __device__ __forceinline__ void nodes_add_batch(NodeList& L, int lane, bool has,
 		}
 	}
 }
-__device__ __forceinline__ void nodes_load(NodeList& L, int lane, const SimNodeDev* src, int cnt)
+__device__ __forceinline__ void nodes_load(NodeList& L, int lane, const SimNodeDev* src, int cnt, uint32_t* bits)
 {
+	L.bits = bits;
 	L.cnt = cnt; L.low = 0; L.low_mask = 0; L.junk = -1; L.l2 = 0; L.dbg_pass = L.dbg_bad = 0;
 	L.score = L.start = L.endi = L.endj = L.top = L.bot = L.left = L.right = 0;
 	if (lane < cnt) {
@@ -240,8 +254,9 @@ __global__ void __launch_bounds__(256) k_sim_forward(SimFwdArgs a, int32_t nunit
 	uint64_t* rowC = a.rowbuf + (int64_t)unit * 2 * a.row_stride;      // [0 .. N]: C of the finished strip's bottom row
 	uint64_t* rowD = rowC + a.row_stride;
 	SimEvent* seg = a.events + ((int64_t)unit * 64 + lane) * a.event_cap;      // my row's segment
+	__shared__ uint32_t start_bits[4][SIM_BITS_WORDS];
 	NodeList L;
-	nodes_load(L, lane, nullptr, 0);
+	nodes_load(L, lane, nullptr, 0, start_bits[threadIdx.x >> 6]);
 	const int64_t thr = a.min_score[unit];
 	const uint64_t Rk = (uint64_t)SIM_R << SIM_SHIFT, QRk = (uint64_t)(SIM_Q + SIM_R) << SIM_SHIFT;
 	const int nstrips = (M + 63) / 64;
@@ -429,8 +444,10 @@ __global__ void __launch_bounds__(LDS ? 64 : 256) k_sim_resweep(SimResweepArgs a
 	const int mm = rq.mm, nn = rq.nn;
 	// node list: lane k < cnt holds node k
 	NodeList L;
-	if (rq.active == 1) nodes_load(L, lane, a.nodes_in + (int64_t)slot * SIM_K, rq.node_count);
-	else nodes_load(L, lane, a.nodes + (int64_t)unit * SIM_K, a.node_count[unit]);
+	__shared__ uint32_t start_bits[LDS ? 1 : 4][SIM_BITS_WORDS];
+	uint32_t* const bits = start_bits[LDS ? 0 : (threadIdx.x >> 6)];
+	if (rq.active == 1) nodes_load(L, lane, a.nodes_in + (int64_t)slot * SIM_K, rq.node_count, bits);
+	else nodes_load(L, lane, a.nodes + (int64_t)unit * SIM_K, a.node_count[unit], bits);
 	int phase, i, m1, n1, rl, cl, floor_score, nround;
 	bool grow_rows, grow_cols, positive;
 	if (rq.active == 1) {
