@@ -1,26 +1,28 @@
-// fasim-longtarget_amd/csrc/sim.hip -- row f3, first step: the forward sweep of classic SIM (the reference's -F path) on gfx950.
+// fasim-longtarget_amd/csrc/sim.hip -- row f3: classic SIM (the reference's -F path, sim.h:410-1143) on gfx950.
 //
-// What it replaces: the first double loop of SIM() (sim.h:506-571): affine-gap local alignment scores of the whole
-// (lncRNA x target) matrix where every cell also carries the START POINT of its best alignment, with the reference's
+// Two kernels.  k_sim_forward replaces the first double loop of SIM() (sim.h:506-571): affine-gap local alignment scores of the
+// whole (lncRNA x target) matrix where every cell also carries the START POINT of its best alignment, with the reference's
 // tie-break ORDER (sim.h:481-493): larger score, then larger start row, then larger start column.  Cells whose score
 // exceeds the threshold go to the K = 50 node list (addnode, sim.h:99-148), which is order dependent (row-major).
+// k_sim_resweep (further down) replaces the re-sweeps of the rectangle an alignment may have influenced, which follow each of
+// the K tracebacks (sim.h:884-1141); the tracebacks themselves are host code (host_sim.cpp, SimUnit::next_round).
 //
-// Layout: one wave64 per unit.  The query rows are cut into strips of 64 (lane = row); a strip is swept over the target
-// columns as a wavefront (lane l works on column step - l), so the left neighbour is the lane's own previous cell and the
-// upper / diagonal neighbours arrive from lane l-1 by a wave shift.  Lane 63 leaves the strip's bottom row (C and D per
+// k_sim_forward, layout: one wave64 per unit.  The query rows are cut into strips of 64 (lane = row); a strip is swept over the
+// target columns as a wavefront (lane l works on column step - l), so the left neighbour is the lane's own previous cell and
+// the upper / diagonal neighbours arrive from lane l-1 by a wave shift.  Lane 63 leaves the strip's bottom row (C and D per
 // column) in a per-unit row buffer in HBM, which lane 0 of the next strip reads back 64 columns at a time.
 //
 // The node list lives in the wave too: lane k holds node k (score, start, end, bounding box).  A lane appends the cells of
 // ITS row that pass the threshold to the row's own segment of a per-unit scratch buffer (columns ascend with the steps), and
-// after each strip the wave replays the 64 segments in row order through addnode: the search for a node with the same start
-// point is one compare + ballot, the eviction of the first lowest-score node a wave minimum over (score, lane).  That is
-// the row-major order of the reference without a sort, and nothing but the 50 nodes ever leaves the GPU.
+// after each strip the wave replays the 64 segments in row order through addnode, 64 events of one row at a time
+// (nodes_add_batch below).  That is the row-major order of the reference without a sort, and nothing but the 50 nodes ever
+// leaves the GPU.
 //
 // A DP state = one 64-bit key  (score + SIM_BIAS) << 32 | start_row << 16 | start_col,  so ORDER is an unsigned 64-bit max
 // and "score - k" is a subtraction in the top field.  Scores are the reference's x10 values (match 50, mismatch -40, gap
-// open 120, extension 40).  Limits: query and target at most 65534 long (16-bit start fields, and the re-sweep starts lines at row M + 1 / column N + 1; 8191 until round 3).
-// Four units per 256-thread workgroup (one wave each: the waves share nothing).
-// Integer DP: no MFMA.  Plain 64-bit VALU arithmetic, not yet tuned.
+// open 120, extension 40).  Limits: query and target at most 65534 long (16-bit start fields, and a re-sweep starts lines at
+// row M + 1 / column N + 1; 8191 until round 3).  Four units per 256-thread workgroup (one wave each: the waves share nothing).
+// Integer DP: no MFMA; 64-bit VALU arithmetic, DPP scans (see DESIGN.md section 9 for what a step costs).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernels.h"
