@@ -130,6 +130,9 @@ int sim_resweep_rounds(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, 
 	// the clock every eighth line), or a number of 64-cell steps when FASIM_SIM_BUDGET is set (tests).  A unit that needs more (a
 	// re-sweep of most of the matrix) carries on in the next launch: the average round of H19 x 5 kb takes 10 k steps, the heaviest
 	// unit of a 500 kb record 12 M steps in all.
+	// ticks of the device's constant-rate clock (wall_clock64 in the kernel) per millisecond: 100 MHz on MI300 / MI355X
+	int wall_khz = 0;
+	if (hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, E->device) != hipSuccess || wall_khz <= 0) wall_khz = 100000;
 	const char* budget_s = getenv("FASIM_SIM_BUDGET");       // (tests: a small budget exercises suspend / resume)
 	const int budget_env = budget_s && atoi(budget_s) > 0 ? atoi(budget_s) : 0;
 	static const bool debug = getenv("FASIM_SIM_DEBUG") != nullptr;
@@ -200,7 +203,7 @@ int sim_resweep_rounds(fasim_engine* E, const uint8_t* tcodes_dev, int tstride, 
 			a.rowS = E->sim_rowst.as<uint64_t>(); a.rowG = a.rowS + (size_t)n * row_stride;
 			a.col_stride = col_stride; a.row_stride = row_stride;
 			a.nodes = E->sim_nodes.as<SimNodeDev>(); a.node_count = E->sim_cnt.as<int32_t>();
-			a.state = E->sim_state.as<SimSweepState>(); a.budget = budget_env ? budget_env : (1 << 20); a.slice_ticks = budget_env ? ((int64_t)1 << 40) : (everywhere > 1024 ? 5000000 : 6000000); a.debug = debug ? E->sim_debug.as<uint64_t>() : nullptr;
+			a.state = E->sim_state.as<SimSweepState>(); a.budget = budget_env ? budget_env : (1 << 20); a.slice_ticks = budget_env ? ((int64_t)1 << 40) : (int64_t)(everywhere > 1024 ? 50 : 60) * wall_khz; a.debug = debug ? E->sim_debug.as<uint64_t>() : nullptr;
 			const double tl0 = now_s();
 			hipError_t he;
 			{ TimedScope ts(E, 7); he = launch_sim_resweep(a, active, everywhere <= 256 /* one unit per CU: all at once */, E->st); }
