@@ -36,7 +36,16 @@ constexpr int64_t SIM_MATCH = 50, SIM_MISMATCH = -40, SIM_Q = 120, SIM_R = 40;
 
 __device__ __forceinline__ uint64_t sim_key(int64_t s, uint32_t i, uint32_t j) { return ((uint64_t)(s + SIM_BIAS) << SIM_SHIFT) | ((uint64_t)i << SIM_FIELD) | (uint64_t)j; }
 __device__ __forceinline__ int64_t sim_score(uint64_t k) { return (int64_t)(k >> SIM_SHIFT) - SIM_BIAS; }
-__device__ __forceinline__ uint64_t umax64(uint64_t a, uint64_t b) { return a > b ? a : b; }
+// Unsigned 64-bit maximum of two keys in ONE instruction: read as doubles, positive normal numbers order like their bit patterns
+// (a key is (score + 2^23) << 32 | ..., with score + 2^23 in [2^22, 2^25): exponent field 4 ... 9, never a denormal, NaN or
+// infinity; 0, the "no value" of the scans, is +0.0, below every key), and the maximum of two of them is a copy of one of them.
+// v_cmp_gt_u64 + 2 x v_cndmask otherwise, fourteen times per 64-cell step.
+__device__ __forceinline__ uint64_t umax64(uint64_t a, uint64_t b)
+{
+	double r;
+	asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(__longlong_as_double((long long)a)), "v"(__longlong_as_double((long long)b)));
+	return (uint64_t)__double_as_longlong(r);
+}
 __device__ __forceinline__ uint64_t shfl_up64(uint64_t v)
 {
 	const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, 1, 64), hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), 1, 64);
