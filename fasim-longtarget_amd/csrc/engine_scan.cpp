@@ -625,7 +625,8 @@ int scan_core(fasim_engine* E, const char* const* rnas, const int32_t* rna_lens,
 			{
 				// -F: the finish half of classic SIM is ~40 ms of host work per unit and nothing else needs the cores meanwhile
 				const int all = E->host_threads_explicit ? E->host_threads_total : usable_cores();
-				w->sim_threads = std::max(1, all / (int)std::max<size_t>(1, std::min<size_t>((size_t)nworkers, items.size())));
+				// (the batches' host halves rarely coincide: a quarter of the workers share the cores; 5 Mb: 38.4 -> 35.2 s, all cores each: 36.1 s)
+				w->sim_threads = std::max(1, all / (int)std::max<size_t>(1, std::min<size_t>((size_t)nworkers, items.size()) / 4));
 			}
 			HIPOK(hipSetDevice(E->device));
 			int rc = upload(w, w->enc_ids, encs.data(), sizeof(int) * nenc); if (rc) return rc;
