@@ -46,11 +46,6 @@ __device__ __forceinline__ uint64_t umax64(uint64_t a, uint64_t b)
 	asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(__longlong_as_double((long long)a)), "v"(__longlong_as_double((long long)b)));
 	return (uint64_t)__double_as_longlong(r);
 }
-__device__ __forceinline__ uint64_t shfl_up64(uint64_t v)
-{
-	const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, 1, 64), hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), 1, 64);
-	return ((uint64_t)hi << 32) | lo;
-}
 __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l)
 {
 	const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
@@ -90,9 +85,9 @@ __device__ __forceinline__ int wave_max_i32(int v)
 
 // ---- the node list (sim.h:99-148) in a wave: lane k < cnt holds node k.  addnode: a known start point is updated (a strictly
 // larger score moves the end point; the bounding box grows), a new one is appended or, with K nodes present, overwrites the FIRST
-// node of lowest score whatever its own score is.  In random sequence about a third of all cells are such events (the x10
-// scores are compared with the unscaled threshold, so every isolated match is one), which makes this replay -- serial by
-// definition -- the critical path of both kernels: the lowest score and the lanes that hold it are kept wave-uniform, so an
+// node of lowest score whatever its own score is.  In random sequence 8 % of the cells of the first sweep are such events (the
+// x10 scores are compared with the unscaled threshold) and 80 % of the cells of a re-sweep (threshold 1), which makes this
+// replay -- serial by definition -- the critical path of both kernels: the lowest score and the lanes that hold it are kept wave-uniform, so an
 // eviction is a count-trailing-zeros, and the wave-wide minimum is only recomputed when that set runs empty.
 struct NodeList {
 	int score, start, endi, endj, top, bot, left, right;      // start = start row << 16 | start column
@@ -297,7 +292,7 @@ __global__ void __launch_bounds__(256) k_sim_forward(SimFwdArgs a, int32_t nunit
 			const int shifted = __shfl_up(tcode, 1, 64);
 			tcode = lane == 0 ? newcode : shifted;
 			// C and D of the row above in my column: lane-1's result of the previous step; lane 0: row 0 or the previous strip
-			uint64_t upC = shfl_up64(myC), upD = shfl_up64(myD);
+			uint64_t upC = dpp_up64(myC), upD = dpp_up64(myD);
 			if (lane == 0) {
 				if (strip == 0) { upC = sim_key(0, 0, (uint32_t)j); upD = sim_key(-SIM_Q, 0, (uint32_t)j); }       // sim.h:497-505
 				else { upC = readlane64(bufC, step & 63); upD = readlane64(bufD, step & 63); }
@@ -367,11 +362,6 @@ __device__ __forceinline__ void wave_publish() { __builtin_amdgcn_s_waitcnt(0); 
 struct SweepCarry { uint64_t corner, pre; };
 struct SweepCell { uint64_t c, across, g; bool valid; int pos; };
 
-__device__ __forceinline__ uint64_t shfl_up64n(uint64_t v, int d)
-{
-	const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, d, 64), hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d, 64);
-	return ((uint64_t)hi << 32) | lo;
-}
 __device__ __forceinline__ uint64_t key_sub(uint64_t k, int64_t s) { return k - ((uint64_t)s << SIM_SHIFT); }
 __device__ __forceinline__ int key_i(uint64_t k) { return (int)((k >> SIM_FIELD) & 0xffff); }
 __device__ __forceinline__ int key_j(uint64_t k) { return (int)(k & 0xffff); }
